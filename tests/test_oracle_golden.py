@@ -1,0 +1,155 @@
+"""The CPU oracle against the golden vectors taken from the reference's own classes."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import REPO, load_golden, rel_err
+from mad_amd.config import load_cfg
+from mad_amd.init import seeded_state_dict
+from mad_amd.unet_spec import spec_from_cfg
+from oracle.scheduler_ref import RefScheduler
+from oracle.translation_ref import RefTranslation, keep_mask, tensor_dilate
+from oracle.unet_ref import unet_forward
+
+torch.set_grad_enabled(False)
+
+
+def _oracle_unet(cfg_file, seed=1):
+    cfg = load_cfg(os.path.join(REPO, "configs", cfg_file))
+    spec = spec_from_cfg(cfg)
+    sd = seeded_state_dict(spec, seed)
+    kw = dict(img_resolution=spec.img_resolution, model_channels=spec.model_channels,
+              channel_mult=spec.channel_mult, num_blocks=spec.num_blocks, label_dim=spec.label_dim)
+    return spec, sd, kw
+
+
+@pytest.mark.parametrize("tag,cfg_file", [("tiny", "model_tiny.yaml"), ("64", "model_64_64.yaml"),
+                                          ("256", "model_256_256.yaml")])
+def test_unet_matches_reference(tag, cfg_file):
+    g = load_golden(f"unet_{tag}.npz")
+    spec, sd, kw = _oracle_unet(cfg_file, int(g["seed"]))
+    taps = {}
+    y = unet_forward(sd, torch.from_numpy(g["x"]), torch.from_numpy(g["t"]),
+                     torch.from_numpy(g["labels"]), taps=taps, **kw)
+    assert rel_err(y, g["y"]) < 2e-5
+    for k in g.files:
+        if k.startswith("tap:"):
+            assert rel_err(taps[k[4:]], g[k]) < 2e-5, k
+    if "y_per_sample" in g.files:
+        y2 = unet_forward(sd, torch.from_numpy(g["x"]), torch.from_numpy(g["t_per_sample"]),
+                          torch.from_numpy(g["labels"]), **kw)
+        assert rel_err(y2, g["y_per_sample"]) < 2e-5
+
+
+def test_schedule_anchors():
+    s = RefScheduler("ddpm")
+    ac = s.alphas_cumprod
+    np.testing.assert_allclose(ac[[0, 179, 699, 999]].numpy(),
+                               [0.9999, 0.7122501, 6.96611e-3, 4.03583e-5], rtol=2e-6)
+    s.set_timesteps(1000)
+    np.testing.assert_allclose(float(s.variance(1)), 5.453479e-5, rtol=2e-6)
+    np.testing.assert_allclose(float(s.variance(999)), 1.999996e-2, rtol=2e-6)
+    d = RefScheduler("ddim")
+    d.set_timesteps(50)
+    assert d.timesteps.tolist() == list(range(980, -1, -20))
+    d.set_inverse_timesteps(50)
+    assert d.timesteps.tolist() == list(range(0, 1000, 20))
+
+
+@pytest.mark.parametrize("kind", ["ddpm", "ddim"])
+def test_sampler_matches_reference(kind):
+    g = load_golden("sampler.npz")
+    s = RefScheduler(kind)
+    np.testing.assert_array_equal(s.alphas_cumprod.numpy(), g[f"{kind}/alphas_cumprod"])
+    for n in (1000, 50):
+        s.set_timesteps(n)
+        np.testing.assert_array_equal(s.timesteps.numpy(), g[f"{kind}/timesteps_{n}"])
+        s.set_inverse_timesteps(n)
+        np.testing.assert_array_equal(s.timesteps.numpy(), g[f"{kind}/inverse_timesteps_{n}"])
+    checked = 0
+    for n in (1000, 50):
+        s.set_timesteps(n)
+        ratio = 1000 // n
+        for t in sorted({(t // ratio) * ratio for t in (0, 1, 179, 699, 999)}):
+            key = f"{kind}/n{n}/t{t}"
+            T = lambda nm: torch.from_numpy(g[f"{key}/{nm}"])
+            for pt in ("epsilon", "sample"):
+                s.config.prediction_type = pt
+                r = s.step(T("eps"), t, T("sample"), eta=0.01, variance_noise=T("noise"))
+                np.testing.assert_array_equal(r.prev_sample.numpy(), g[f"{key}/{pt}/step"])
+                np.testing.assert_array_equal(r.pred_original_sample.numpy(), g[f"{key}/{pt}/x0"])
+                r = s.step(T("eps"), t, T("sample"), eta=0.01, variance_noise=T("noise"),
+                           original_image=T("orig"), mask=T("mask"))
+                np.testing.assert_array_equal(r.prev_sample.numpy(), g[f"{key}/{pt}/step_masked"])
+                if kind == "ddim":
+                    r = s.step(T("eps"), t, T("sample"), eta=1.0, variance_noise=T("noise"),
+                               use_clipped_model_output=True)
+                    np.testing.assert_array_equal(r.prev_sample.numpy(), g[f"{key}/{pt}/step_eta1_clipped"])
+                if t > 0:
+                    z = s.compute_eps(T("eps"), t, T("sample"), T("next"), eta=0.01)
+                    np.testing.assert_array_equal(z.numpy(), g[f"{key}/{pt}/compute_eps"])
+                r = s.ddim_inverse_step(T("eps"), t, T("sample"))
+                np.testing.assert_array_equal(r.prev_sample.numpy(), g[f"{key}/{pt}/inverse"])
+                checked += 1
+            s.config.prediction_type = "epsilon"
+            np.testing.assert_array_equal(
+                s.add_noise(T("orig"), T("noise"), torch.tensor([t])).numpy(), g[f"{key}/add_noise"])
+    assert checked >= 16
+    # the clamp is exercised: some predicted x0 sit exactly on +-1
+    assert (np.abs(g[f"{kind}/n1000/t699/epsilon/x0"]) == 1.0).any()
+
+
+def test_sampler_errors():
+    d = RefScheduler("ddim")
+    with pytest.raises(ValueError):
+        d.step(torch.zeros(1), 10, torch.zeros(1))
+    p = RefScheduler("ddpm")
+    p.set_timesteps(1000)
+    with pytest.raises(AssertionError):
+        p.compute_eps(torch.zeros(1), 0, torch.zeros(1), torch.zeros(1))
+    p.config.prediction_type = "bogus"
+    with pytest.raises(ValueError):
+        p.step(torch.zeros(1), 10, torch.zeros(1))
+
+
+def test_masks_match_reference():
+    g = load_golden("masks.npz")
+    lab = torch.from_numpy(g["label_map"])
+    np.testing.assert_array_equal(keep_mask(lab).numpy(), g["keep_all"])
+    np.testing.assert_array_equal(keep_mask(lab, dilate=False).numpy(), g["keep_nodilate"])
+    for k in g.files:
+        if k.startswith("keep_") and k[5].isdigit():
+            comps = [int(c) for c in k[5:].split("_")]
+            np.testing.assert_array_equal(keep_mask(lab, comps).numpy(), g[k], err_msg=k)
+    b = torch.from_numpy(g["dilate_in"])
+    np.testing.assert_array_equal(tensor_dilate(b, 5).numpy(), g["dilate_5"])
+    np.testing.assert_array_equal(tensor_dilate(b, 11).numpy(), g["dilate_11"])
+
+
+@pytest.mark.parametrize("kind", ["ddpm", "ddim"])
+def test_trajectory_matches_reference(kind):
+    g = load_golden("trajectory.npz")
+    spec, sd, kw = _oracle_unet("model_tiny.yaml", 1)
+    model = lambda x, t, labels: unet_forward(sd, x, t, labels, **kw)
+    steps, start = int(g[f"{kind}/sample_steps"]), int(g[f"{kind}/start"])
+    image = torch.from_numpy(g[f"{kind}/image"])
+    draws = iter(torch.from_numpy(np.concatenate([g[f"{kind}/enc_draws"], g[f"{kind}/gen_draws"]])))
+    tr = RefTranslation(RefScheduler(kind), 2, sample_steps=steps, eta=0.01,
+                        randn=lambda shape: next(draws))
+    src, tgt = tr.process_label(0, 2), tr.process_label(1, 2)
+    eps_list = tr.encode(image, src, model, start_from_step=start)
+    ref_eps = torch.from_numpy(g[f"{kind}/eps_list"])
+    assert eps_list.shape == ref_eps.shape
+    # compute_eps divides by sigma_t (down to 1e-4 for DDIM eta=0.01): compare per step, relative
+    for i in range(eps_list.shape[1]):
+        assert rel_err(eps_list[:, i], ref_eps[:, i]) < 5e-3, i
+    # 24 (DDPM) / 50 (DDIM) chained denoiser calls: fp32 summation-order noise of the conv
+    # backend compounds along the chain, so the end images agree to ~1e-4, not to the last bit
+    tol = 2e-4
+    out = tr.generate(model, eps_list=ref_eps, class_label=src, source_image=image, start_from_step=start)
+    assert float((out - torch.from_numpy(g[f"{kind}/out_same_label"])).abs().max()) < tol
+    out = tr.generate(model, eps_list=ref_eps, class_label=tgt, source_image=image,
+                      source_mask=torch.from_numpy(g[f"{kind}/mask"]), start_from_step=start)
+    assert float((out - torch.from_numpy(g[f"{kind}/out_target_masked"])).abs().max()) < tol
