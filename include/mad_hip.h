@@ -1,0 +1,163 @@
+/*
+ * mad_hip.h -- C ABI of libmad_hip.so: the MI355X (gfx950) kernels of the MAD denoising path.
+ *
+ * The reference has no FFI of its own for this path: it is pure Python calling torch operators
+ * (cuDNN / cuBLAS / xformers behind them).  Each entry point below therefore names the reference
+ * operator site (file:line under /root/reference) whose arithmetic it replaces; a binding for it
+ * is a few lines of ctypes.
+ *
+ * Conventions
+ *   - every pointer is a device pointer owned by the caller; nothing here allocates or frees;
+ *   - every call only enqueues work on `stream` (a hipStream_t passed as void*; NULL = default
+ *     stream) and returns immediately;
+ *   - return value 0 = ok, non-zero = rejected before launch; mad_last_error() gives the reason
+ *     (thread-local string);
+ *   - activations inside the denoiser are NHWC ("channels last"): element (b, y, x, c) at
+ *     ((b*H + y)*W + x)*C + c; dtype is MAD_BF16 (bf16 storage, fp32 accumulate) or MAD_F32;
+ *   - tensors at the sampler level are NCHW fp32, as in the reference.
+ */
+#ifndef MAD_HIP_H
+#define MAD_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MAD_BF16 0
+#define MAD_F32 1
+
+int mad_version(void);
+const char* mad_last_error(void);
+
+/* ------------------------------------------------------------------ sampler (NCHW fp32) ---- */
+
+#define MAD_ALGO_DDPM 0
+#define MAD_ALGO_DDIM 1
+#define MAD_PRED_EPSILON 0
+#define MAD_PRED_SAMPLE 1
+#define MAD_PRED_V 2
+#define MAD_OP_STEP 0        /* x_t -> x_{t-1}                         */
+#define MAD_OP_COMPUTE_EPS 1 /* noise that maps x_t to a given x_{t-1} */
+#define MAD_OP_INVERSE 2     /* deterministic DDIM inversion step      */
+
+/* Scalars of one sampler update, computed on the host in fp32 exactly as the reference computes
+ * them from alphas_cumprod (scheduler.py:341-346,374-380 DDPM; :45-50,89,106 DDIM). */
+typedef struct mad_sampler_coef {
+    int32_t algo, pred_type, op;
+    int32_t clip;             /* clamp predicted x0 to +-clip_range (scheduler.py:367-370)      */
+    int32_t use_clipped;      /* DDIM: re-derive eps from the clamped x0 (scheduler.py:81-85)   */
+    int32_t add_variance;     /* step: add std*noise (t > 0, and eta > 0 for DDIM)              */
+    int32_t known_noise;      /* step, masked: the known part gets sqrt(1-a_prev)*noise (t > 0) */
+    float sqrt_a_t;           /* alpha_prod_t ** 0.5                                            */
+    float sqrt_b_t;           /* (1 - alpha_prod_t) ** 0.5                                      */
+    float c0, c1;             /* DDPM: x0 and x_t coefficients of the posterior mean            */
+    float std;                /* sigma_t                                                        */
+    float sqrt_a_prev;        /* alpha_prod_t_prev ** 0.5                                       */
+    float sqrt_b_prev;        /* (1 - alpha_prod_t_prev) ** 0.5                                 */
+    float dir_coef;           /* DDIM: (1 - a_prev - std^2) ** 0.5                              */
+    float clip_range;
+    float eps_div;            /* compute_eps divisor (std, or 1 when std/eta is 0)              */
+} mad_sampler_coef;
+
+/* One coalesced elementwise pass over (B,C,H,W) fp32.
+ * Replaces CustomDDPMScheduler.step (scheduler.py:293-423), .compute_eps (:425-493),
+ * .ddim_inverse_step (:526-585) and the CustomDDIMScheduler counterparts (:12-131, :133-197,
+ * :230-289).  `noise`, `original`, `mask`, `next_sample`, `x0_out` may be NULL where the
+ * operation does not use them.  mask is (mask_batch,1,H,W) with mask_batch 1 or B. */
+int mad_sampler_update(const mad_sampler_coef* coef, const float* model_output, const float* sample,
+                       const float* noise, const float* original, const float* mask,
+                       const float* next_sample, float* out, float* x0_out, int B, int C, int H,
+                       int W, int mask_batch, void* stream);
+
+/* out = sa*x0 + sb*noise; with mask: out = mask*(sa*x0 + sb*noise) + (1-mask)*x0.
+ * Replaces scheduler.add_noise as used by sample_xt (translation.py:699-706, 781-789). */
+int mad_add_noise(const float* x0, const float* noise, const float* mask, float* out, float sa,
+                  float sb, int B, int C, int H, int W, int mask_batch, void* stream);
+
+/* out = clamp(x,-1,1) [/2 + 0.5 when normalize] (translation.py:870-873). */
+int mad_finalize_image(const float* x, float* out, int normalize, size_t n, void* stream);
+
+/* dst[b,c,y,x] = src[b,c,y,x] where mask[(b),0,y,x] > 0 (translation.py:820-821). */
+int mad_masked_copy(float* dst, const float* src, const float* mask, int B, int C, int H, int W,
+                    int mask_batch, void* stream);
+
+/* Label map (H,W) uint8 -> keep-mask (H,W) float, 1 = keep the source pixel.  `comps` lists the
+ * active component values already sorted by priority; `dilate` enables the 21x21 eye ring.
+ * Replaces the tensor branch of process_mask + tensor_dilate (translation.py:54-58, 234-273). */
+int mad_keep_mask(const uint8_t* label_map, float* keep, int H, int W, const int32_t* comps,
+                  int ncomps, int dilate, void* stream);
+
+/* ------------------------------------------------------------------ denoiser pieces -------- */
+
+/* y = act_out(act_in(x) @ W^T + bias) in fp32; x (rows,K), W (N,K) row-major, bias may be NULL.
+ * act: 0 none, 1 SiLU.  `accumulate` adds into y instead of overwriting (the class-label term).
+ * Replaces Linear.forward (model.py:60-64) for map_layer0/1, map_label and every block's affine. */
+int mad_linear_f32(const float* x, const float* W, const float* bias, float* y, int rows, int K,
+                   int N, int act_in, int act_out, int accumulate, void* stream);
+
+/* emb[b, :half] = cos(t[b]*freqs), emb[b, half:] = sin(t[b]*freqs)  (model.py:392-400).
+ * t has t_count (1 or rows) entries; freqs is the fp32 table (1/10000)**(i/half). */
+int mad_pos_embedding(const float* t, int t_count, const float* freqs, float* emb, int rows,
+                      int half, void* stream);
+
+/* First convolution: x NCHW fp32 (B,Cin<=4,H,W) -> y NHWC (B,H,W,Cout), 3x3 pad 1, fp32 weights
+ * (Cout,Cin,3,3) and bias.  Replaces enc.{R}x{R}_conv (model.py:506-508, 580-582). */
+int mad_conv_in(const float* x, const float* w, const float* bias, void* y, int dtype, int B,
+                int Cin, int H, int W, int Cout, void* stream);
+
+/* Last convolution: x NHWC (B,H,W,Cin) -> y NCHW fp32 (B,Cout<=4,H,W), 3x3 pad 1, fp32 weights
+ * laid out (Cout,3,3,Cin) and bias.  Replaces out_conv (model.py:549-551, 589). */
+int mad_conv_out(const void* x, int dtype, const float* w, const float* bias, float* y, int B,
+                 int Cin, int H, int W, int Cout, void* stream);
+
+#define MAD_RES_NONE 0
+#define MAD_RES_SAME 1 /* residual (B,H,W,Cout)                                   */
+#define MAD_RES_UP 2   /* residual (B,H/2,W/2,Cout), nearest-neighbour x2         */
+#define MAD_RES_DOWN 3 /* residual (B,2H,2W,Cout), 2x2 mean                       */
+
+/* Implicit-GEMM convolution on MFMA, stride 1, ksize 1 or 3 (pad ksize/2):
+ *   y[b,oy,ox,n] = bias[n] + sum_{ky,kx,c} in(b, oy+ky-p, ox+kx-p, c) * w[n,ky,kx,c] (+ residual)
+ * `in` is the channel concatenation of x1 (C1 channels) and x2 (C2 channels, may be NULL/0), both
+ * NHWC at (H,W) -- or at (H/2,W/2) read through nearest-neighbour x2 when `upsample` is set.
+ * w is (Cout,ksize,ksize,C1+C2) in `dtype`; bias fp32.  C1, C2 must be multiples of 64 and Cout a
+ * multiple of 64.  Replaces Conv2d.forward (model.py:116-166) for the 3x3 convs, the 1x1
+ * skip/qkv/proj convs, the `up` resample (model.py:147-153), the skip concat (model.py:586-587)
+ * and the residual adds (model.py:353, 375). */
+int mad_conv2d(const void* x1, int C1, const void* x2, int C2, const void* w, const float* bias,
+               const void* residual, int res_mode, void* y, int dtype, int B, int H, int W,
+               int Cout, int ksize, int upsample, void* stream);
+
+/* GroupNorm statistics, pass 1: per-(sample, split, channel) sum and sum of squares over the
+ * split's pixels of the concatenation of x1 (C1) and x2 (C2).  partial is fp32
+ * (B, nsplit, C1+C2, 2).  HW must be a multiple of nsplit. */
+int mad_gn_partial(const void* x1, int C1, const void* x2, int C2, int dtype, float* partial, int B,
+                   int HW, int nsplit, void* stream);
+
+/* GroupNorm statistics, pass 2: reduce the partials per group and fold mean, rstd, the affine
+ * gain/offset and the optional AdaGN modulation into one (a, d) pair per (sample, channel):
+ *   y = x*a + d  ==  shift + ((x-mean)*rstd*gamma + beta) * (scale + 1)
+ * ada is fp32 with row stride ada_stride: ada[b*ada_stride + c] = scale, ada[... + C + c] = shift
+ * (scale first: model.py:343-346); NULL for a plain GroupNorm.  coef is fp32 (B, C, 2).
+ * Replaces GroupNorm.forward (model.py:182-190) statistics. */
+int mad_gn_finalize(const float* partial, const float* gamma, const float* beta, const float* ada,
+                    int ada_stride, float* coef, int B, int C, int groups, int HW, int nsplit,
+                    float eps, void* stream);
+
+/* y = act(x*a + d) over the concatenation of x1/x2, written as one (B,H,W,C1+C2) tensor
+ * (or (B,H/2,W/2,C) with the 2x2 mean of the activated values when `pool` is set: the `down`
+ * resample of model.py:155-161 applied after norm+SiLU).  act: 0 none, 1 SiLU. */
+int mad_gn_apply(const void* x1, int C1, const void* x2, int C2, const float* coef, void* y,
+                 int dtype, int B, int H, int W, int act, int pool, void* stream);
+
+/* Self-attention over L = H*W positions, head_dim 64: qkv is NHWC (B,L,3*C) with channel
+ * head*192 + {0..63 q, 64..127 k, 128..191 v}; out is (B,L,C) with channel head*64 + d.
+ * softmax(q.k/8) in fp32.  Replaces model.py:357-375 / AttentionOp (model.py:199-212). */
+int mad_attention(const void* qkv, void* out, int dtype, int B, int L, int heads, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MAD_HIP_H */

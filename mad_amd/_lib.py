@@ -1,0 +1,73 @@
+"""ctypes binding of libmad_hip.so (the C ABI declared in include/mad_hip.h).
+
+There is no fallback: if the shared library is missing the import of this module raises, and
+every operator in ``mad_amd.ops`` raises ``RuntimeError`` on a non-zero status from the library.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmad_hip.so")
+
+MAD_BF16, MAD_F32 = 0, 1
+ALGO_DDPM, ALGO_DDIM = 0, 1
+PRED_EPSILON, PRED_SAMPLE, PRED_V = 0, 1, 2
+OP_STEP, OP_COMPUTE_EPS, OP_INVERSE = 0, 1, 2
+RES_NONE, RES_SAME, RES_UP, RES_DOWN = 0, 1, 2, 3
+
+
+class SamplerCoef(Structure):
+    """Mirror of ``mad_sampler_coef``."""
+    _fields_ = [("algo", c_int32), ("pred_type", c_int32), ("op", c_int32), ("clip", c_int32),
+                ("use_clipped", c_int32), ("add_variance", c_int32), ("known_noise", c_int32),
+                ("sqrt_a_t", c_float), ("sqrt_b_t", c_float), ("c0", c_float), ("c1", c_float),
+                ("std", c_float), ("sqrt_a_prev", c_float), ("sqrt_b_prev", c_float),
+                ("dir_coef", c_float), ("clip_range", c_float), ("eps_div", c_float)]
+
+
+# name -> (restype, argtypes); must list every function include/mad_hip.h declares
+SIGNATURES = {
+    "mad_version": (c_int, []),
+    "mad_last_error": (c_char_p, []),
+    "mad_sampler_update": (c_int, [POINTER(SamplerCoef)] + [c_void_p] * 8 + [c_int] * 5 + [c_void_p]),
+    "mad_add_noise": (c_int, [c_void_p] * 4 + [c_float, c_float] + [c_int] * 5 + [c_void_p]),
+    "mad_finalize_image": (c_int, [c_void_p, c_void_p, c_int, c_size_t, c_void_p]),
+    "mad_masked_copy": (c_int, [c_void_p] * 3 + [c_int] * 5 + [c_void_p]),
+    "mad_keep_mask": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p]),
+    "mad_linear_f32": (c_int, [c_void_p] * 4 + [c_int] * 6 + [c_void_p]),
+    "mad_pos_embedding": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "mad_conv_in": (c_int, [c_void_p] * 4 + [c_int] * 6 + [c_void_p]),
+    "mad_conv_out": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p] + [c_int] * 5 + [c_void_p]),
+    "mad_conv2d": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p]
+                   + [c_int] * 7 + [c_void_p]),
+    "mad_gn_partial": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "mad_gn_finalize": (c_int, [c_void_p] * 4 + [c_int, c_void_p] + [c_int] * 5 + [c_float, c_void_p]),
+    "mad_gn_apply": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
+    "mad_attention": (c_int, [c_void_p, c_void_p] + [c_int] * 4 + [c_void_p]),
+}
+
+
+def _load() -> ctypes.CDLL:
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `make -C mad_amd/csrc` (or "
+            "`python -c 'import __graft_entry__ as g; g.build()'`). mad_amd has no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the library lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+
+
+def check(status: int, what: str) -> None:
+    """Turn a non-zero C status into the Python exception convention of the reference."""
+    if status != 0:
+        msg = lib.mad_last_error()
+        raise RuntimeError(f"{what} failed ({status}): {msg.decode() if msg else ''}")

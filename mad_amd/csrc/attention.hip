@@ -1,0 +1,183 @@
+// Self-attention of the UNet blocks, flash style (no L x L matrix in memory), head_dim 64.
+//
+// One wave owns 32 queries; a workgroup of NW waves shares each 32-key K/V tile through LDS.
+// Scores are computed transposed, S^T = K . Q^T (keys on the accumulator rows, queries on the
+// lanes), so a query's softmax statistics are lane-local (16 registers + one cross-half
+// exchange) and the probability tile is already laid out as the B operand of the second product
+// O^T = V^T . P^T -- no shuffle or LDS round trip for P.  fp32 softmax, fp32 accumulation.
+#include "mma.h"
+
+namespace mad {
+
+constexpr int HD = 64;   // head dim
+constexpr int KT = 32;   // keys per tile
+
+template <typename T> struct AttnLds;
+// bf16: K rows are 128 bytes (8 chunks), V rows 128 bytes, unswizzled V for column gathers.
+template <> struct AttnLds<bf16_t> { static constexpr int ROW = 128; };
+template <> struct AttnLds<float> { static constexpr int ROW = 256; };
+
+template <typename T, int NW>
+__global__ __launch_bounds__(NW * 64) void attention_kernel(const T* __restrict__ qkv, T* __restrict__ out, int L,
+                                                             int heads) {
+    constexpr int VEC = Elem<T>::VEC;
+    constexpr int ROW = AttnLds<T>::ROW;          // bytes per key row in LDS
+    constexpr int CHUNKS = ROW / 16;              // 16-byte chunks per row
+    constexpr int NT = NW * 64;
+    __shared__ __attribute__((aligned(16))) unsigned char k_lds[KT * ROW];
+    __shared__ __attribute__((aligned(16))) unsigned char v_lds[KT * ROW];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.z, head = blockIdx.y;
+    const int C3 = heads * 3 * HD;
+    const int q0 = (blockIdx.x * NW + wave) * 32;
+    const int qi = lane & 31, fh = lane >> 5;
+    const T* base = qkv + (size_t)b * L * C3 + head * 3 * HD;
+
+    // Q fragments (B operand): chunk pair kk covers d = kk*2*VEC .. ; scale by 1/sqrt(64) (exact)
+    constexpr int NKK = CHUNKS / 2;
+    uint4 qf[NKK];
+    {
+        const T* qrow = base + (size_t)(q0 + qi) * C3;
+#pragma unroll
+        for (int kk = 0; kk < NKK; ++kk) {
+            Vec16<T> v;
+            v.load(qrow + (2 * kk + fh) * VEC);
+            float f[VEC];
+            v.unpack(f);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) f[i] *= 0.125f;
+            v.pack(f);
+            qf[kk] = v.raw;
+        }
+    }
+
+    f32x16 o[2];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { o[0][e] = 0.0f; o[1][e] = 0.0f; }
+    float m_run = -1.0e30f, l_run = 0.0f;
+
+    for (int k0 = 0; k0 < L; k0 += KT) {
+        __syncthreads();   // previous tile fully consumed
+        for (int c = tid; c < KT * CHUNKS; c += NT) {
+            const int r = c / CHUNKS, ch = c % CHUNKS;
+            const T* krow = base + (size_t)(k0 + r) * C3 + HD;
+            const uint4 kv = *reinterpret_cast<const uint4*>(krow + ch * VEC);
+            const uint4 vv = *reinterpret_cast<const uint4*>(krow + HD + ch * VEC);
+            const int sw = (ROW == 128) ? (ch ^ ((r >> 1) & 7)) : (ch ^ (r & 15));
+            *reinterpret_cast<uint4*>(k_lds + r * ROW + sw * 16) = kv;
+            *reinterpret_cast<uint4*>(v_lds + r * ROW + ch * 16) = vv;
+        }
+        __syncthreads();
+
+        // S^T[key][query] = sum_d K[key][d] * Q[query][d]
+        f32x16 s;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) s[e] = 0.0f;
+#pragma unroll
+        for (int kk = 0; kk < NKK; ++kk) {
+            const int ch = 2 * kk + fh;
+            const int sw = (ROW == 128) ? (ch ^ ((qi >> 1) & 7)) : (ch ^ (qi & 15));
+            const uint4 kf = *reinterpret_cast<const uint4*>(k_lds + qi * ROW + sw * 16);
+            mma_chunk<T>(s, kf, qf[kk]);
+        }
+
+        // online softmax for this lane's query: 16 keys here, the other 16 in lane^32
+        float tmax = s[0];
+#pragma unroll
+        for (int e = 1; e < 16; ++e) tmax = fmaxf(tmax, s[e]);
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+        const float m_new = fmaxf(m_run, tmax);
+        const float alpha = __expf(m_run - m_new);
+        float psum = 0.0f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { s[e] = __expf(s[e] - m_new); psum += s[e]; }
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { o[0][e] *= alpha; o[1][e] *= alpha; }
+
+        // O^T[d][query] += sum_key V[key][d] * P^T[key][query]
+        if constexpr (sizeof(T) == 2) {
+            // k-step st uses accumulator registers 8st..8st+7 as the B fragment; element j of lane
+            // half h is key 16st + 8(j>>2) + 4h + (j&3), so the A fragment gathers V at those keys.
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                bf16x8 pf;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pf[j] = (__bf16)s[8 * st + j];
+#pragma unroll
+                for (int dh = 0; dh < 2; ++dh) {
+                    bf16x8 vf;
+                    const int d = dh * 32 + qi;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int key = 16 * st + 8 * (j >> 2) + 4 * fh + (j & 3);
+                        const unsigned short bits = *reinterpret_cast<const unsigned short*>(v_lds + key * ROW + d * 2);
+                        vf[j] = __builtin_bit_cast(__bf16, bits);
+                    }
+                    o[dh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[dh], 0, 0, 0);
+                }
+            }
+        } else {
+            // fp32: one 32x32x2 MFMA per accumulator register; lane half h supplies key acc_row(j)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int key = (j & 3) + 8 * (j >> 2) + 4 * fh;
+#pragma unroll
+                for (int dh = 0; dh < 2; ++dh) {
+                    const float vv = *reinterpret_cast<const float*>(v_lds + key * ROW + (dh * 32 + qi) * 4);
+                    o[dh] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv, s[j], o[dh], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    const float l = l_run + __shfl_xor(l_run, 32);
+    const float inv = 1.0f / l;
+    const int C = heads * HD;
+    T* orow = out + ((size_t)b * L + q0 + qi) * C + head * HD;
+#pragma unroll
+    for (int dh = 0; dh < 2; ++dh)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int d = dh * 32 + 8 * g + 4 * fh;
+            if constexpr (sizeof(T) == 2) {
+                ushort4 pk;
+                pk.x = f32_to_bf16(o[dh][4 * g + 0] * inv);
+                pk.y = f32_to_bf16(o[dh][4 * g + 1] * inv);
+                pk.z = f32_to_bf16(o[dh][4 * g + 2] * inv);
+                pk.w = f32_to_bf16(o[dh][4 * g + 3] * inv);
+                *reinterpret_cast<ushort4*>(orow + d) = pk;
+            } else {
+                float4 pk = make_float4(o[dh][4 * g + 0] * inv, o[dh][4 * g + 1] * inv, o[dh][4 * g + 2] * inv,
+                                        o[dh][4 * g + 3] * inv);
+                *reinterpret_cast<float4*>(orow + d) = pk;
+            }
+        }
+}
+
+}  // namespace mad
+
+using namespace mad;
+
+extern "C" int mad_attention(const void* qkv, void* out, int dtype, int B, int L, int heads, void* stream) {
+    MAD_REQUIRE(qkv && out, "mad_attention: null pointer");
+    MAD_REQUIRE(dtype == MAD_BF16 || dtype == MAD_F32, "mad_attention: bad dtype %d", dtype);
+    MAD_REQUIRE(B > 0 && heads > 0 && L >= 64 && L % 64 == 0, "mad_attention: L=%d must be a multiple of 64", L);
+    hipStream_t s = (hipStream_t)stream;
+    if (L % 128 == 0) {
+        dim3 grid(L / 128, heads, B);
+        if (dtype == MAD_BF16)
+            hipLaunchKernelGGL((attention_kernel<bf16_t, 4>), grid, dim3(256), 0, s, (const bf16_t*)qkv, (bf16_t*)out, L, heads);
+        else
+            hipLaunchKernelGGL((attention_kernel<float, 4>), grid, dim3(256), 0, s, (const float*)qkv, (float*)out, L, heads);
+    } else {
+        dim3 grid(L / 64, heads, B);
+        if (dtype == MAD_BF16)
+            hipLaunchKernelGGL((attention_kernel<bf16_t, 2>), grid, dim3(128), 0, s, (const bf16_t*)qkv, (bf16_t*)out, L, heads);
+        else
+            hipLaunchKernelGGL((attention_kernel<float, 2>), grid, dim3(128), 0, s, (const float*)qkv, (float*)out, L, heads);
+    }
+    return check_launch("mad_attention");
+}

@@ -1,0 +1,66 @@
+// Shared helpers for the gfx950 kernels of libmad_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/mad_hip.h"
+
+namespace mad {
+
+void set_error(const char* fmt, ...);
+int check_launch(const char* what);
+
+#define MAD_REQUIRE(cond, ...)              \
+    do {                                    \
+        if (!(cond)) {                      \
+            mad::set_error(__VA_ARGS__);    \
+            return 1;                       \
+        }                                   \
+    } while (0)
+
+typedef unsigned short bf16_t;  // raw bf16 bits
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+
+// Round-to-nearest-even conversion; a plain cast lowers to v_cvt_pk_bf16_f32 on gfx950 and keeps
+// NaNs as NaNs, which integer bit tricks do not.
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+    __bf16 b = (__bf16)f;
+    return __builtin_bit_cast(unsigned short, b);
+}
+
+template <typename T> struct Elem;
+template <> struct Elem<bf16_t> {
+    static constexpr int VEC = 8;  // elements per 16 bytes
+    __device__ static __forceinline__ float load(bf16_t v) { return bf16_to_f32(v); }
+    __device__ static __forceinline__ bf16_t store(float f) { return f32_to_bf16(f); }
+};
+template <> struct Elem<float> {
+    static constexpr int VEC = 4;
+    __device__ static __forceinline__ float load(float v) { return v; }
+    __device__ static __forceinline__ float store(float f) { return f; }
+};
+
+// 16-byte vector of T, unpacked to floats.
+template <typename T> struct Vec16 {
+    static constexpr int N = Elem<T>::VEC;
+    uint4 raw;
+    __device__ __forceinline__ void load(const T* p) { raw = *reinterpret_cast<const uint4*>(p); }
+    __device__ __forceinline__ void store(T* p) const { *reinterpret_cast<uint4*>(p) = raw; }
+    __device__ __forceinline__ void unpack(float* f) const {
+        const T* e = reinterpret_cast<const T*>(&raw);
+#pragma unroll
+        for (int i = 0; i < N; ++i) f[i] = Elem<T>::load(e[i]);
+    }
+    __device__ __forceinline__ void pack(const float* f) {
+        T* e = reinterpret_cast<T*>(&raw);
+#pragma unroll
+        for (int i = 0; i < N; ++i) e[i] = Elem<T>::store(f[i]);
+    }
+};
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+
+}  // namespace mad

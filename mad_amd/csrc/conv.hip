@@ -1,0 +1,377 @@
+// Convolutions of the denoiser.
+//
+//   conv_igemm_kernel  3x3 / 1x1 stride-1 convolution as an implicit GEMM on MFMA:
+//                      out[m][n] = sum_k A[m][k] * Wt[n][k],  m = (b,oy,ox), k = (ky,kx,c).
+//                      Block tile 128 (pixels) x BN (output channels), K-tile = 128 bytes of
+//                      channels of one tap.  Both operand tiles are brought in by asynchronous
+//                      16-byte global->LDS copies (one tile in flight while the previous one is
+//                      multiplied); padding pixels and rows past M read a zero page.  LDS rows are
+//                      128 bytes, XOR-swizzled on the source side so the ds_read_b128 fragment
+//                      reads are bank-conflict free.  The epilogue stages the fp32 tile through
+//                      LDS and writes whole 16-byte chunks with bias and residual added.
+//   conv_in_kernel     first layer (Cin = 3, NCHW fp32 in, NHWC out): direct, bandwidth bound.
+//   conv_out_kernel    last layer (Cout = 3, NHWC in, NCHW fp32 out): direct, bandwidth bound.
+#include "mma.h"
+
+namespace mad {
+
+__device__ __attribute__((aligned(256))) const unsigned char g_zero_page[256] = {0};
+
+struct ConvArgs {
+    const void* x1; const void* x2; const void* w; const float* bias; const void* residual; void* y;
+    int C1, C2, B, H, W, Cout, ksize, upsample, res_mode;
+    int M;          // B*H*W
+    int Hs, Ws;     // source spatial size (H/2, W/2 when upsample)
+    int mtiles, ntiles;
+};
+
+constexpr int BM = 128;
+constexpr int ROWB = 128;   // bytes per LDS row = one K-tile of one operand row
+
+template <int BN> constexpr int conv_lds_bytes() {
+    constexpr int stage = 2 * (BM + BN) * ROWB;
+    constexpr int epi = BM * (BN + 4) * 4;
+    return stage > epi ? stage : epi;
+}
+
+template <typename T, int BN>
+__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
+    constexpr int VEC = Elem<T>::VEC;             // elements per 16-byte chunk
+    constexpr int CK = ROWB / (int)sizeof(T);     // channels per K-tile
+    constexpr int TN = BN / 64;                   // 32-wide accumulator tiles per wave along n
+    constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // XCD-aware tile order: blocks id, id+8, ... share an XCD (and its L2); give each XCD a
+    // contiguous range of tiles so neighbouring pixel tiles (shared halo rows) and the n-tiles of
+    // one pixel tile hit the same L2.
+    const int nwg = a.mtiles * a.ntiles;
+    const int id = blockIdx.x;
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = id & 7;
+    const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (id >> 3);
+    const int mt = logical / a.ntiles, nt = logical % a.ntiles;
+    const int m0 = mt * BM, n0 = nt * BN;
+
+    const int Ctot = a.C1 + a.C2;
+    const int cchunks = Ctot / CK;
+    const int ntaps = a.ksize * a.ksize;
+    const int nk = ntaps * cchunks;
+    const int pad = a.ksize >> 1;
+    const int HW = a.H * a.W;
+
+    // ---- per-thread DMA assignment: instruction j of this wave covers rows (j*4+wave)*8 .. +7
+    const int lrow = lane >> 3, pchunk = lane & 7;
+    int a_oy[4], a_ox[4], a_b[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int m = m0 + (j * 4 + wave) * 8 + lrow;
+        if (m < a.M) {
+            const int b = m / HW, rem = m - b * HW;
+            a_b[j] = b; a_oy[j] = rem / a.W; a_ox[j] = rem - a_oy[j] * a.W;
+        } else {
+            a_b[j] = -1; a_oy[j] = 0; a_ox[j] = 0;
+        }
+    }
+
+    const unsigned smem_base = lds_addr(smem);
+    auto stage = [&](int kt, int buf) {
+        const int tap = kt / cchunks, cc = kt - tap * cchunks;
+        const int ky = tap / a.ksize, kx = tap - ky * a.ksize;
+        const int c0 = cc * CK;
+        const T* src; int cs, coff;
+        if (c0 < a.C1) { src = (const T*)a.x1; cs = a.C1; coff = c0; }
+        else { src = (const T*)a.x2; cs = a.C2; coff = c0 - a.C1; }
+        const unsigned abuf = smem_base + buf * (A_BYTES + B_BYTES);
+        const unsigned bbuf = abuf + A_BYTES;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = (j * 4 + wave) * 8 + lrow;
+            const int lchunk = pchunk ^ ((r >> 1) & 7);
+            const int iy = a_oy[j] + ky - pad, ix = a_ox[j] + kx - pad;
+            const bool ok = a_b[j] >= 0 && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+            // clamp so the address is always in range, then select the zero page for padding
+            const int cy = min(max(iy, 0), a.H - 1), cx = min(max(ix, 0), a.W - 1);
+            const int sy = a.upsample ? cy >> 1 : cy, sx = a.upsample ? cx >> 1 : cx;
+            const int bb = max(a_b[j], 0);
+            const T* p = src + ((size_t)((bb * a.Hs + sy) * a.Ws + sx)) * cs + coff + lchunk * VEC;
+            const void* g = ok ? (const void*)p : (const void*)g_zero_page;
+            glds16(g, __builtin_amdgcn_readfirstlane(abuf + (j * 4 + wave) * 8 * ROWB));
+        }
+#pragma unroll
+        for (int j = 0; j < BN / 32; ++j) {
+            const int r = (j * 4 + wave) * 8 + lrow;
+            const int lchunk = pchunk ^ ((r >> 1) & 7);
+            const T* g = (const T*)a.w + ((size_t)(n0 + r) * ntaps + tap) * Ctot + c0 + lchunk * VEC;
+            glds16(g, __builtin_amdgcn_readfirstlane(bbuf + (j * 4 + wave) * 8 * ROWB));
+        }
+    };
+
+    f32x16 acc[2][TN];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+    const int frow = lane & 31, fh = lane >> 5;
+    stage(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        // every wave waits for its own copies of tile kt, then the barrier publishes the tile and
+        // also means every wave is done reading the buffer tile kt+1 is about to overwrite
+        dma_wait_all();
+        __syncthreads();
+        if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
+        const unsigned char* abuf = smem + (kt & 1) * (A_BYTES + B_BYTES);
+        const unsigned char* bbuf = abuf + A_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            uint4 af[2], bfr[TN];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int r = wm * 64 + i * 32 + frow;
+                af[i] = *reinterpret_cast<const uint4*>(abuf + r * ROWB + (((2 * kk + fh) ^ ((r >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int r = wn * (BN / 2) + j * 32 + frow;
+                bfr[j] = *reinterpret_cast<const uint4*>(bbuf + r * ROWB + (((2 * kk + fh) ^ ((r >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) mma_chunk<T>(acc[i][j], af[i], bfr[j]);
+        }
+    }
+
+    // ---- epilogue: fp32 tile -> LDS -> coalesced 16-byte stores with bias / residual
+    __syncthreads();
+    float* ctile = reinterpret_cast<float*>(smem);
+    constexpr int CLD = BN + 4;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int r = wm * 64 + i * 32 + acc_row(e, lane);
+                const int c = wn * (BN / 2) + j * 32 + (lane & 31);
+                ctile[r * CLD + c] = acc[i][j][e];
+            }
+    __syncthreads();
+    constexpr int CPR = BN / VEC;            // 16-byte output chunks per tile row
+    constexpr int RPP = 256 / CPR;           // rows per pass
+    const int er = tid / CPR, ec = (tid % CPR) * VEC;
+    float bias_v[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) bias_v[i] = a.bias ? a.bias[n0 + ec + i] : 0.0f;
+    const T* res = (const T*)a.residual;
+    T* y = (T*)a.y;
+    for (int r = er; r < BM; r += RPP) {
+        const int m = m0 + r;
+        if (m >= a.M) break;
+        float v[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; i += 4) {
+            const float4 t = *reinterpret_cast<const float4*>(ctile + r * CLD + ec + i);
+            v[i] = t.x + bias_v[i]; v[i + 1] = t.y + bias_v[i + 1];
+            v[i + 2] = t.z + bias_v[i + 2]; v[i + 3] = t.w + bias_v[i + 3];
+        }
+        if (a.res_mode == MAD_RES_SAME) {
+            Vec16<T> rv; rv.load(res + (size_t)m * a.Cout + n0 + ec);
+            float f[VEC]; rv.unpack(f);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) v[i] += f[i];
+        } else if (a.res_mode == MAD_RES_UP) {
+            const int b = m / HW, rem = m - b * HW, oy = rem / a.W, ox = rem - oy * a.W;
+            const size_t rp = ((size_t)b * (a.H >> 1) + (oy >> 1)) * (a.W >> 1) + (ox >> 1);
+            Vec16<T> rv; rv.load(res + rp * a.Cout + n0 + ec);
+            float f[VEC]; rv.unpack(f);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) v[i] += f[i];
+        } else if (a.res_mode == MAD_RES_DOWN) {
+            const int b = m / HW, rem = m - b * HW, oy = rem / a.W, ox = rem - oy * a.W;
+            float s[VEC];
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) s[i] = 0.0f;
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 2; ++dx) {
+                    const size_t rp = ((size_t)b * (2 * a.H) + (2 * oy + dy)) * (2 * a.W) + (2 * ox + dx);
+                    Vec16<T> rv; rv.load(res + rp * a.Cout + n0 + ec);
+                    float f[VEC]; rv.unpack(f);
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) s[i] += f[i];
+                }
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) v[i] = fmaf(s[i], 0.25f, v[i]);
+        }
+        Vec16<T> o; o.pack(v);
+        o.store(y + (size_t)m * a.Cout + n0 + ec);
+    }
+}
+
+// --------------------------------------------------------------------------- first layer
+// 64 consecutive pixels per block; thread (p = tid&63, cg = tid>>6) computes channel chunks
+// cg, cg+4, ... of pixel p from its 27 input taps held in registers.
+template <typename T, int Cin>
+__global__ __launch_bounds__(256) void conv_in_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                       const float* __restrict__ bias, T* __restrict__ y, int B,
+                                                       int H, int W, int Cout) {
+    constexpr int VEC = Elem<T>::VEC;
+    extern __shared__ __attribute__((aligned(16))) float wl[];   // [Cout][Cin*9] then bias[Cout]
+    constexpr int K = Cin * 9;
+    for (int i = threadIdx.x; i < Cout * K; i += 256) wl[i] = w[i];
+    for (int i = threadIdx.x; i < Cout; i += 256) wl[Cout * K + i] = bias[i];
+    __syncthreads();
+    const int HW = H * W;
+    const size_t m = (size_t)blockIdx.x * 64 + (threadIdx.x & 63);
+    if (m >= (size_t)B * HW) return;
+    const int b = (int)(m / HW), rem = (int)(m % HW), oy = rem / W, ox = rem % W;
+    float in[K];
+#pragma unroll
+    for (int c = 0; c < Cin; ++c)
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int iy = oy + ky - 1, ix = ox + kx - 1;
+                const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
+                in[c * 9 + ky * 3 + kx] = ok ? x[((size_t)(b * Cin + c) * H + iy) * W + ix] : 0.0f;
+            }
+    for (int chunk = threadIdx.x >> 6; chunk < Cout / VEC; chunk += 4) {
+        float v[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            const int n = chunk * VEC + i;
+            float s = wl[Cout * K + n];
+#pragma unroll
+            for (int k = 0; k < K; ++k) s = fmaf(in[k], wl[n * K + k], s);
+            v[i] = s;
+        }
+        Vec16<T> o; o.pack(v);
+        o.store(y + m * Cout + chunk * VEC);
+    }
+}
+
+// --------------------------------------------------------------------------- last layer
+// One thread per output pixel, all (<= 4) output channels; weights (Cout,3,3,Cin) fp32 in LDS are
+// read as wave-wide broadcasts.
+template <typename T>
+__global__ __launch_bounds__(256) void conv_out_kernel(const T* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, float* __restrict__ y, int B,
+                                                        int Cin, int H, int W, int Cout) {
+    constexpr int VEC = Elem<T>::VEC;
+    extern __shared__ __attribute__((aligned(16))) float wl[];   // [Cout][9][Cin]
+    for (int i = threadIdx.x; i < Cout * 9 * Cin; i += 256) wl[i] = w[i];
+    __syncthreads();
+    const int HW = H * W;
+    const size_t m = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (m >= (size_t)B * HW) return;
+    const int b = (int)(m / HW), rem = (int)(m % HW), oy = rem / W, ox = rem % W;
+    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int tap = 0; tap < 9; ++tap) {
+        const int iy = oy + tap / 3 - 1, ix = ox + tap % 3 - 1;
+        if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
+        const T* px = x + ((size_t)(b * H + iy) * W + ix) * Cin;
+        for (int c = 0; c < Cin; c += VEC) {
+            Vec16<T> v; v.load(px + c);
+            float f[VEC]; v.unpack(f);
+#pragma unroll
+            for (int co = 0; co < 4; ++co) {
+                if (co < Cout) {
+                    const float* ww = wl + (co * 9 + tap) * Cin + c;
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) acc[co] = fmaf(f[i], ww[i], acc[co]);
+                }
+            }
+        }
+    }
+    for (int co = 0; co < Cout; ++co) y[((size_t)(b * Cout + co) * H + oy) * W + ox] = acc[co] + bias[co];
+}
+
+template <typename T, int BN> static int launch_igemm(const ConvArgs& a, hipStream_t s) {
+    constexpr int lds = conv_lds_bytes<BN>();
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<T, BN>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((conv_igemm_kernel<T, BN>), dim3(a.mtiles * a.ntiles), dim3(256), lds, s, a);
+    return check_launch("mad_conv2d");
+}
+
+}  // namespace mad
+
+using namespace mad;
+
+extern "C" int mad_conv2d(const void* x1, int C1, const void* x2, int C2, const void* w, const float* bias,
+                          const void* residual, int res_mode, void* y, int dtype, int B, int H, int W, int Cout,
+                          int ksize, int upsample, void* stream) {
+    MAD_REQUIRE(x1 && w && y, "mad_conv2d: null pointer");
+    MAD_REQUIRE(dtype == MAD_BF16 || dtype == MAD_F32, "mad_conv2d: bad dtype %d", dtype);
+    MAD_REQUIRE(ksize == 1 || ksize == 3, "mad_conv2d: ksize must be 1 or 3, got %d", ksize);
+    MAD_REQUIRE(C1 > 0 && C1 % 64 == 0 && C2 >= 0 && C2 % 64 == 0 && (C2 == 0 || x2),
+                "mad_conv2d: C1=%d, C2=%d must be multiples of 64 (x2 given when C2 > 0)", C1, C2);
+    MAD_REQUIRE(Cout > 0 && Cout % 64 == 0, "mad_conv2d: Cout=%d must be a multiple of 64", Cout);
+    MAD_REQUIRE(B > 0 && H > 0 && W > 0 && (size_t)B * H * W < (1u << 31), "mad_conv2d: bad shape B=%d H=%d W=%d", B, H, W);
+    MAD_REQUIRE(!upsample || (H % 2 == 0 && W % 2 == 0), "mad_conv2d: upsample needs even H, W");
+    MAD_REQUIRE(res_mode >= MAD_RES_NONE && res_mode <= MAD_RES_DOWN && (res_mode == MAD_RES_NONE || residual),
+                "mad_conv2d: bad residual mode %d", res_mode);
+    MAD_REQUIRE(res_mode != MAD_RES_UP || (H % 2 == 0 && W % 2 == 0), "mad_conv2d: RES_UP needs even H, W");
+    ConvArgs a;
+    a.x1 = x1; a.x2 = C2 ? x2 : x1; a.w = w; a.bias = bias; a.residual = residual; a.y = y;
+    a.C1 = C1; a.C2 = C2; a.B = B; a.H = H; a.W = W; a.Cout = Cout; a.ksize = ksize; a.upsample = upsample;
+    a.res_mode = res_mode; a.M = B * H * W;
+    a.Hs = upsample ? H / 2 : H; a.Ws = upsample ? W / 2 : W;
+    a.mtiles = (a.M + BM - 1) / BM;
+    const bool wide = (Cout % 128 == 0);
+    a.ntiles = Cout / (wide ? 128 : 64);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == MAD_BF16) return wide ? launch_igemm<bf16_t, 128>(a, s) : launch_igemm<bf16_t, 64>(a, s);
+    return wide ? launch_igemm<float, 128>(a, s) : launch_igemm<float, 64>(a, s);
+}
+
+extern "C" int mad_conv_in(const float* x, const float* w, const float* bias, void* y, int dtype, int B, int Cin,
+                           int H, int W, int Cout, void* stream) {
+    MAD_REQUIRE(x && w && bias && y, "mad_conv_in: null pointer");
+    MAD_REQUIRE(dtype == MAD_BF16 || dtype == MAD_F32, "mad_conv_in: bad dtype %d", dtype);
+    MAD_REQUIRE(Cin == 3, "mad_conv_in: Cin=%d, only 3 input channels are built", Cin);
+    MAD_REQUIRE(Cout > 0 && Cout % 8 == 0 && Cout <= 512, "mad_conv_in: Cout=%d must be a multiple of 8, <= 512", Cout);
+    MAD_REQUIRE(B > 0 && H > 0 && W > 0, "mad_conv_in: bad shape");
+    const size_t M = (size_t)B * H * W;
+    const size_t lds = ((size_t)Cout * Cin * 9 + Cout) * sizeof(float);
+    dim3 grid((unsigned)((M + 63) / 64));
+    if (dtype == MAD_BF16)
+        hipLaunchKernelGGL((conv_in_kernel<bf16_t, 3>), grid, dim3(256), lds, (hipStream_t)stream, x, w, bias,
+                           (bf16_t*)y, B, H, W, Cout);
+    else
+        hipLaunchKernelGGL((conv_in_kernel<float, 3>), grid, dim3(256), lds, (hipStream_t)stream, x, w, bias,
+                           (float*)y, B, H, W, Cout);
+    return check_launch("mad_conv_in");
+}
+
+extern "C" int mad_conv_out(const void* x, int dtype, const float* w, const float* bias, float* y, int B, int Cin,
+                            int H, int W, int Cout, void* stream) {
+    MAD_REQUIRE(x && w && bias && y, "mad_conv_out: null pointer");
+    MAD_REQUIRE(dtype == MAD_BF16 || dtype == MAD_F32, "mad_conv_out: bad dtype %d", dtype);
+    MAD_REQUIRE(Cout >= 1 && Cout <= 4, "mad_conv_out: Cout=%d must be 1..4", Cout);
+    MAD_REQUIRE(Cin > 0 && Cin % 8 == 0 && (size_t)Cout * 9 * Cin * 4 <= 64 * 1024,
+                "mad_conv_out: Cin=%d must be a multiple of 8 with weights fitting 64 KiB of LDS", Cin);
+    MAD_REQUIRE(B > 0 && H > 0 && W > 0, "mad_conv_out: bad shape");
+    const size_t M = (size_t)B * H * W;
+    const size_t lds = (size_t)Cout * 9 * Cin * sizeof(float);
+    dim3 grid((unsigned)((M + 255) / 256));
+    if (dtype == MAD_BF16)
+        hipLaunchKernelGGL(conv_out_kernel<bf16_t>, grid, dim3(256), lds, (hipStream_t)stream, (const bf16_t*)x, w,
+                           bias, y, B, Cin, H, W, Cout);
+    else
+        hipLaunchKernelGGL(conv_out_kernel<float>, grid, dim3(256), lds, (hipStream_t)stream, (const float*)x, w, bias,
+                           y, B, Cin, H, W, Cout);
+    return check_launch("mad_conv_out");
+}

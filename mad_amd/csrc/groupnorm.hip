@@ -1,0 +1,246 @@
+// GroupNorm for NHWC activations: statistics in two passes (partial sums, then a finalize that
+// folds mean/rstd/gamma/beta and the AdaGN scale/shift into one multiply-add per channel), and an
+// apply pass y = act(x*a + d) that can also average 2x2 pixels (the encoder's downsample).
+// All of it is HBM-bound: 16-byte vector accesses, wave-level reductions, fp32 statistics.
+#include "common.h"
+
+namespace mad {
+
+// ------------------------------------------------------------------------------- partial sums
+// grid (nsplit, B), 256 threads.  Chunk = 16 bytes = VEC channels of one pixel.  A thread keeps the
+// same channel chunk for every pixel it visits, so its sums stay in registers.
+template <typename T>
+__global__ __launch_bounds__(256) void gn_partial_kernel(const T* __restrict__ x1, int C1, const T* __restrict__ x2,
+                                                          int C2, float* __restrict__ partial, int HW, int nsplit) {
+    constexpr int VEC = Elem<T>::VEC;
+    const int C = C1 + C2;
+    const int cpr = C / VEC;                 // chunks per pixel
+    const int rows = 256 / cpr > 0 ? 256 / cpr : 1;
+    const int b = blockIdx.y, split = blockIdx.x;
+    const int pix_per_split = HW / nsplit;
+    const int p0 = split * pix_per_split;
+    extern __shared__ __attribute__((aligned(16))) float red[];   // [rows][cpr][2*VEC] (cpr<=256)
+    float s[VEC], q[VEC];
+    // cpr may exceed 256 (C > 2048 for bf16 never happens here; for fp32 C=1536 gives 384): loop chunks
+    for (int cbase = 0; cbase < cpr; cbase += 256) {
+        const int t = threadIdx.x;
+        const int my_rows = (cpr >= 256) ? 1 : rows;
+        const int chunk = cbase + ((cpr >= 256) ? t : t % cpr);
+        const int row = (cpr >= 256) ? 0 : t / cpr;
+        const bool active = chunk < cpr && row < my_rows;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) s[i] = q[i] = 0.0f;
+        if (active) {
+            const int c = chunk * VEC;
+            const T* src;
+            int cs, coff;
+            if (c < C1) { src = x1; cs = C1; coff = c; } else { src = x2; cs = C2; coff = c - C1; }
+            src += ((size_t)b * HW) * cs + coff;
+            for (int p = p0 + row; p < p0 + pix_per_split; p += my_rows) {
+                Vec16<T> v;
+                v.load(src + (size_t)p * cs);
+                float f[VEC];
+                v.unpack(f);
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) { s[i] += f[i]; q[i] = fmaf(f[i], f[i], q[i]); }
+            }
+        }
+        if (cpr >= 256) {
+            if (active) {
+                float* dst = partial + (((size_t)b * nsplit + split) * C + chunk * VEC) * 2;
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) { dst[2 * i] = s[i]; dst[2 * i + 1] = q[i]; }
+            }
+        } else {
+            __syncthreads();
+            if (active) {
+                float* r = red + ((size_t)row * cpr + (chunk - cbase)) * 2 * VEC;
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) { r[2 * i] = s[i]; r[2 * i + 1] = q[i]; }
+            }
+            __syncthreads();
+            // fixed-order reduction over the rows: deterministic
+            for (int j = threadIdx.x; j < cpr * 2 * VEC; j += 256) {
+                float acc = 0.0f;
+                for (int r = 0; r < my_rows; ++r) acc += red[(size_t)r * cpr * 2 * VEC + j];
+                partial[(((size_t)b * nsplit + split) * C) * 2 + j] = acc;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------- finalize
+// grid (B), 256 threads.  One thread per group computes mean/rstd in fp64 from the partials, then
+// all threads write the per-channel (a, d) pairs.
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ partial,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta,
+                                                           const float* __restrict__ ada, int ada_stride,
+                                                           float* __restrict__ coef, int C, int groups, int HW,
+                                                           int nsplit, float eps) {
+    __shared__ float mean_s[64], rstd_s[64];
+    const int b = blockIdx.x;
+    const int cpg = C / groups;
+    // 4 threads per group share the (split, channel) pairs, combined in a fixed order
+    const int g = threadIdx.x >> 2, sub = threadIdx.x & 3;
+    if (g < groups) {
+        double s = 0.0, q = 0.0;
+        const int items = nsplit * cpg;
+        for (int it = sub; it < items; it += 4) {
+            const int sp = it / cpg, c = g * cpg + it % cpg;
+            const float* p = partial + (((size_t)b * nsplit + sp) * C + c) * 2;
+            s += (double)p[0];
+            q += (double)p[1];
+        }
+        s += __shfl_xor(s, 1); q += __shfl_xor(q, 1);
+        s += __shfl_xor(s, 2); q += __shfl_xor(q, 2);
+        if (sub == 0) {
+            const double n = (double)HW * cpg;
+            const double mean = s / n;
+            double var = q / n - mean * mean;
+            if (var < 0.0) var = 0.0;
+            mean_s[g] = (float)mean;
+            rstd_s[g] = (float)(1.0 / sqrt(var + (double)eps));
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const int gg = c / cpg;
+        const float rg = rstd_s[gg] * gamma[c];
+        float a = rg;
+        float d = beta[c] - mean_s[gg] * rg;
+        if (ada) {
+            const float sc = ada[(size_t)b * ada_stride + c] + 1.0f;
+            const float sh = ada[(size_t)b * ada_stride + C + c];
+            a = a * sc;
+            d = fmaf(d, sc, sh);
+        }
+        coef[((size_t)b * C + c) * 2] = a;
+        coef[((size_t)b * C + c) * 2 + 1] = d;
+    }
+}
+
+// ------------------------------------------------------------------------------- apply
+template <typename T, bool POOL>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x1, int C1, const T* __restrict__ x2,
+                                                        int C2, const float* __restrict__ coef, T* __restrict__ y,
+                                                        int B, int H, int W, int act) {
+    constexpr int VEC = Elem<T>::VEC;
+    const int C = C1 + C2;
+    const int cpr = C / VEC;
+    const int Ho = POOL ? H / 2 : H, Wo = POOL ? W / 2 : W;
+    const size_t total = (size_t)B * Ho * Wo * cpr;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
+        const int chunk = (int)(idx % cpr);
+        const size_t opix = idx / cpr;                      // b*Ho*Wo + oy*Wo + ox
+        const int b = (int)(opix / ((size_t)Ho * Wo));
+        const int c = chunk * VEC;
+        const T* src;
+        int cs, coff;
+        if (c < C1) { src = x1; cs = C1; coff = c; } else { src = x2; cs = C2; coff = c - C1; }
+        float a[VEC], d[VEC];
+        const float* cf = coef + ((size_t)b * C + c) * 2;
+#pragma unroll
+        for (int i = 0; i < VEC; i += 2) {
+            const float4 v = *reinterpret_cast<const float4*>(cf + 2 * i);
+            a[i] = v.x; d[i] = v.y; a[i + 1] = v.z; d[i + 1] = v.w;
+        }
+        float r[VEC];
+        if (!POOL) {
+            Vec16<T> v;
+            v.load(src + opix * cs + coff);
+            float f[VEC];
+            v.unpack(f);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                const float t = fmaf(f[i], a[i], d[i]);
+                r[i] = act ? silu_f(t) : t;
+            }
+        } else {
+            const int rem = (int)(opix % ((size_t)Ho * Wo));
+            const int oy = rem / Wo, ox = rem % Wo;
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) r[i] = 0.0f;
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 2; ++dx) {
+                    const size_t ip = ((size_t)b * H + (2 * oy + dy)) * W + (2 * ox + dx);
+                    Vec16<T> v;
+                    v.load(src + ip * cs + coff);
+                    float f[VEC];
+                    v.unpack(f);
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) {
+                        const float t = fmaf(f[i], a[i], d[i]);
+                        r[i] += act ? silu_f(t) : t;
+                    }
+                }
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) r[i] *= 0.25f;
+        }
+        Vec16<T> o;
+        o.pack(r);
+        o.store(y + opix * C + c);
+    }
+}
+
+}  // namespace mad
+
+using namespace mad;
+
+extern "C" int mad_gn_partial(const void* x1, int C1, const void* x2, int C2, int dtype, float* partial, int B, int HW,
+                              int nsplit, void* stream) {
+    MAD_REQUIRE(x1 && partial, "mad_gn_partial: null pointer");
+    MAD_REQUIRE(dtype == MAD_BF16 || dtype == MAD_F32, "mad_gn_partial: bad dtype %d", dtype);
+    const int VEC = dtype == MAD_BF16 ? 8 : 4;
+    MAD_REQUIRE(C1 > 0 && C1 % VEC == 0 && C2 >= 0 && C2 % VEC == 0 && (C2 == 0 || x2),
+                "mad_gn_partial: channels must be multiples of %d (C1=%d C2=%d)", VEC, C1, C2);
+    MAD_REQUIRE(B > 0 && HW > 0 && nsplit > 0 && HW % nsplit == 0, "mad_gn_partial: HW=%d not divisible by nsplit=%d",
+                HW, nsplit);
+    const int cpr = (C1 + C2) / VEC;
+    const int rows = cpr >= 256 ? 1 : 256 / cpr;
+    const size_t lds = cpr >= 256 ? 0 : (size_t)rows * cpr * 2 * VEC * sizeof(float);
+    dim3 grid(nsplit, B);
+    if (dtype == MAD_BF16)
+        hipLaunchKernelGGL(gn_partial_kernel<bf16_t>, grid, dim3(256), lds, (hipStream_t)stream, (const bf16_t*)x1, C1,
+                           (const bf16_t*)x2, C2, partial, HW, nsplit);
+    else
+        hipLaunchKernelGGL(gn_partial_kernel<float>, grid, dim3(256), lds, (hipStream_t)stream, (const float*)x1, C1,
+                           (const float*)x2, C2, partial, HW, nsplit);
+    return check_launch("mad_gn_partial");
+}
+
+extern "C" int mad_gn_finalize(const float* partial, const float* gamma, const float* beta, const float* ada,
+                               int ada_stride, float* coef, int B, int C, int groups, int HW, int nsplit, float eps,
+                               void* stream) {
+    MAD_REQUIRE(partial && gamma && beta && coef, "mad_gn_finalize: null pointer");
+    MAD_REQUIRE(B > 0 && C > 0 && groups > 0 && groups <= 64 && C % groups == 0,
+                "mad_gn_finalize: bad C=%d groups=%d", C, groups);
+    MAD_REQUIRE(HW > 0 && nsplit > 0, "mad_gn_finalize: bad HW/nsplit");
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, partial, gamma, beta, ada,
+                       ada_stride, coef, C, groups, HW, nsplit, eps);
+    return check_launch("mad_gn_finalize");
+}
+
+extern "C" int mad_gn_apply(const void* x1, int C1, const void* x2, int C2, const float* coef, void* y, int dtype,
+                            int B, int H, int W, int act, int pool, void* stream) {
+    MAD_REQUIRE(x1 && coef && y, "mad_gn_apply: null pointer");
+    MAD_REQUIRE(dtype == MAD_BF16 || dtype == MAD_F32, "mad_gn_apply: bad dtype %d", dtype);
+    const int VEC = dtype == MAD_BF16 ? 8 : 4;
+    MAD_REQUIRE(C1 > 0 && C1 % VEC == 0 && C2 >= 0 && C2 % VEC == 0 && (C2 == 0 || x2),
+                "mad_gn_apply: channels must be multiples of %d (C1=%d C2=%d)", VEC, C1, C2);
+    MAD_REQUIRE(B > 0 && H > 0 && W > 0 && (!pool || (H % 2 == 0 && W % 2 == 0)), "mad_gn_apply: bad shape");
+    const size_t total = (size_t)B * (pool ? H / 2 : H) * (pool ? W / 2 : W) * ((C1 + C2) / VEC);
+    size_t g = (total + 255) / 256;
+    if (g > 4096) g = 4096;
+    dim3 grid((unsigned)g);
+#define LAUNCH(T, P)                                                                                              \
+    hipLaunchKernelGGL((gn_apply_kernel<T, P>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)x1, C1,        \
+                       (const T*)x2, C2, coef, (T*)y, B, H, W, act)
+    if (dtype == MAD_BF16) { if (pool) LAUNCH(bf16_t, true); else LAUNCH(bf16_t, false); }
+    else { if (pool) LAUNCH(float, true); else LAUNCH(float, false); }
+#undef LAUNCH
+    return check_launch("mad_gn_apply");
+}

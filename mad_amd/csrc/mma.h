@@ -1,0 +1,60 @@
+// MFMA fragment helpers shared by the convolution and attention kernels (gfx950, wave64).
+//
+// Operand convention used throughout: every lane reads ONE 16-byte chunk of a row-major row
+// (lane&31 selects the row, lane>>5 selects which of two adjacent chunks).  For bf16 that is the
+// native A/B layout of v_mfma_f32_32x32x16_bf16 (lane half h holds k = 8h..8h+7).  For fp32 the
+// same two chunks (8 floats) are consumed by four v_mfma_f32_32x32x2_f32, element e of each lane
+// per instruction; the k order inside the sum is permuted identically for A and B, which leaves
+// the product unchanged.  One `mma_chunk` therefore always advances k by 32 bytes of a row.
+#pragma once
+#include "common.h"
+
+namespace mad {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+template <typename T> __device__ __forceinline__ void mma_chunk(f32x16& acc, const uint4& a, const uint4& b);
+
+template <> __device__ __forceinline__ void mma_chunk<bf16_t>(f32x16& acc, const uint4& a, const uint4& b) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc,
+                                                   0, 0, 0);
+}
+
+template <> __device__ __forceinline__ void mma_chunk<float>(f32x16& acc, const uint4& a, const uint4& b) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.x), __uint_as_float(b.x), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.y), __uint_as_float(b.y), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.z), __uint_as_float(b.z), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
+}
+
+// Row of the 32x32 accumulator held in register j of this lane (column = lane & 31).
+__device__ __forceinline__ int acc_row(int j, int lane) { return (j & 3) + 8 * (j >> 2) + 4 * (lane >> 5); }
+
+// Asynchronous 16-byte global -> LDS copy (LDS-DMA).  The LDS destination of a wave-instruction
+// is the wave-uniform byte address `lds_wave_base` + lane*16; the global source is per lane.
+// Issued from inline asm so the compiler does not serialise it against the LDS reads of the
+// tile being multiplied: the caller waits with dma_wait_all() before the barrier that publishes
+// the tile.  M0 carries the LDS base and is saved/restored inside the statement.
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_wave_base) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gsrc), "s"(lds_wave_base)
+        : "memory");
+}
+
+__device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// Byte address inside the workgroup's LDS allocation of a pointer into __shared__ memory.
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+    return (unsigned)(size_t)(__attribute__((address_space(3))) const void*)p;
+}
+
+}  // namespace mad

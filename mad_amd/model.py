@@ -1,0 +1,283 @@
+"""The denoiser: an ADM-style UNet evaluated entirely by the HIP kernels of libmad_hip.so.
+
+Call surface of the reference (``/root/reference/modeling/model.py``):
+
+* ``DhariwalUNet(...)(x, noise_labels, class_labels=None, augment_labels=None) -> (Tensor,)``
+  mirrors ``DhariwalUNet.forward`` (model.py:553-590), parameters named as in the reference
+  ``state_dict``;
+* ``build_model(cfg)`` mirrors model.py:654-668 and returns a ``Denoiser`` whose
+  ``forward(x, t, text=None, class_labels=None) -> Tensor`` is the form the sampling loops call
+  (translation.py:292-297, 732-738, 823-829): ``text`` is accepted and ignored, ``t`` is cast to
+  fp32 (integer timesteps would truncate the sinusoid frequencies, model.py:398) and the 1-tuple
+  is unwrapped.
+
+Inside, activations are NHWC in the compute dtype (bf16 by default, fp32 for parity runs), conv
+weights are repacked once to (Cout, kh, kw, Cin), the qkv rows are permuted so q/k/v are
+contiguous per head, and all per-block AdaGN affines are evaluated by one linear call.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import torch
+from torch import nn
+
+from . import _lib, ops
+from .init import seeded_state_dict
+from .unet_spec import GN_EPS, BlockSpec, UNetSpec, build_spec, gn_groups, spec_from_cfg
+
+Tensor = torch.Tensor
+
+
+class _Params(nn.Module):
+    """Leaf holder giving parameters the reference's dotted names."""
+
+    def __init__(self, shapes: Dict[str, tuple], buffers: Dict[str, tuple] = None):
+        super().__init__()
+        for k, shp in shapes.items():
+            self.register_parameter(k, nn.Parameter(torch.zeros(shp, dtype=torch.float32), requires_grad=False))
+        for k, shp in (buffers or {}).items():
+            self.register_buffer(k, torch.full(shp, 0.25, dtype=torch.float32))
+
+
+def _block_module(b: BlockSpec, emb: int) -> nn.Module:
+    m = nn.Module()
+    ci, co = b.in_channels, b.out_channels
+    rf = {"resample_filter": (1, 1, 2, 2)} if (b.up or b.down) else None
+    m.norm0 = _Params({"weight": (ci,), "bias": (ci,)})
+    m.conv0 = _Params({"weight": (co, ci, 3, 3), "bias": (co,)}, rf)
+    m.affine = _Params({"weight": (2 * co, emb), "bias": (2 * co,)})
+    m.norm1 = _Params({"weight": (co,), "bias": (co,)})
+    m.conv1 = _Params({"weight": (co, co, 3, 3), "bias": (co,)})
+    if b.skip_conv:
+        m.skip = _Params({"weight": (co, ci, 1, 1), "bias": (co,)})
+    elif b.up or b.down:
+        m.skip = _Params({}, rf)
+    if b.attention:
+        m.norm2 = _Params({"weight": (co,), "bias": (co,)})
+        m.qkv = _Params({"weight": (3 * co, co, 1, 1), "bias": (3 * co,)})
+        m.proj = _Params({"weight": (co, co, 1, 1), "bias": (co,)})
+    return m
+
+
+class DhariwalUNet(nn.Module):
+    def __init__(self, img_resolution, in_channels, out_channels, label_dim=0, augment_dim=0,
+                 model_channels=192, channel_mult=(1, 2, 3, 4), channel_mult_emb=4, num_blocks=3,
+                 attn_resolutions=(32, 16, 8), dropout=0.10, label_dropout=0, eff_attn=True,
+                 precision: str = "bf16"):
+        super().__init__()
+        if augment_dim:
+            raise NotImplementedError("augment_dim is 0 on the translation path (model.py:660)")
+        if tuple(attn_resolutions) != (32, 16, 8):
+            raise NotImplementedError("attention resolutions are fixed at 32/16/8 (model.py:444)")
+        self.spec: UNetSpec = build_spec(img_resolution, in_channels, out_channels, label_dim,
+                                         model_channels, channel_mult, num_blocks, channel_mult_emb)
+        s = self.spec
+        self.label_dim = s.label_dim
+        self.precision = precision
+        C, E = s.model_channels, s.emb_channels
+        self.map_layer0 = _Params({"weight": (E, C), "bias": (E,)})
+        self.map_layer1 = _Params({"weight": (E, E), "bias": (E,)})
+        if s.label_dim:
+            self.map_label = _Params({"weight": (E, s.label_dim)})
+        self.enc = nn.ModuleDict()
+        self.dec = nn.ModuleDict()
+        self.enc[s.enc_conv_name.split(".", 1)[1]] = _Params(
+            {"weight": (s.enc_conv_out, s.in_channels, 3, 3), "bias": (s.enc_conv_out,)})
+        for b in s.enc:
+            self.enc[b.name.split(".", 1)[1]] = _block_module(b, E)
+        for b in s.dec:
+            self.dec[b.name.split(".", 1)[1]] = _block_module(b, E)
+        self.out_norm = _Params({"weight": (s.final_channels,), "bias": (s.final_channels,)})
+        self.out_conv = _Params({"weight": (s.out_channels, s.final_channels, 3, 3), "bias": (s.out_channels,)})
+        self._packed = None
+        self._packed_key = None
+        self._register_load_state_dict_post_hook(lambda module, incompatible: module.invalidate())
+
+    # ------------------------------------------------------------------ weights
+    def invalidate(self) -> None:
+        """Drop the repacked device weights (call after changing parameters in place)."""
+        self._packed = None
+
+    def init_seeded(self, seed: int = 0) -> "DhariwalUNet":
+        """Fill every tensor with the reproducible non-zero initialiser of ``mad_amd.init``."""
+        self.load_state_dict(seeded_state_dict(self.spec, seed), strict=True)
+        return self
+
+    def _apply(self, fn, *a, **k):
+        self._packed = None
+        return super()._apply(fn, *a, **k)
+
+    def compute_dtype(self) -> torch.dtype:
+        if self.precision == "bf16":
+            return torch.bfloat16
+        if self.precision == "fp32":
+            return torch.float32
+        raise ValueError(f"precision must be 'bf16' or 'fp32', got {self.precision!r}")
+
+    def _pack(self, device: torch.device) -> dict:
+        dt = self.compute_dtype()
+        key = (str(device), dt)
+        if self._packed is not None and self._packed_key == key:
+            return self._packed
+        s = self.spec
+        sd = {k: v.detach() for k, v in self.state_dict().items()}
+        for v in sd.values():
+            if v.device != device:
+                raise RuntimeError(f"model parameters are on {v.device}, input on {device}: call .to(device)")
+        f32 = lambda k: sd[k].to(torch.float32).contiguous()
+        cw = lambda k: sd[k].to(torch.float32).permute(0, 2, 3, 1).contiguous().to(dt)   # (Cout,kh,kw,Cin)
+        P: dict = {"dtype": dt}
+        half = s.model_channels // 2
+        freqs = torch.arange(half, dtype=torch.float32) / half      # model.py:393-397, evaluated in fp32
+        P["freqs"] = ((1.0 / 10000) ** freqs).to(device)
+        for n in ("map_layer0.weight", "map_layer0.bias", "map_layer1.weight", "map_layer1.bias"):
+            P[n] = f32(n)
+        if s.label_dim:
+            P["map_label.weight"] = f32("map_label.weight")
+        P["in.w"], P["in.b"] = f32(f"{s.enc_conv_name}.weight"), f32(f"{s.enc_conv_name}.bias")
+        aff_w, aff_b, off = [], [], 0
+        blocks: List[dict] = []
+        for b in s.blocks():
+            n = b.name
+            e: dict = {"spec": b, "ada_off": off}
+            off += 2 * b.out_channels
+            aff_w.append(f32(f"{n}.affine.weight"))
+            aff_b.append(f32(f"{n}.affine.bias"))
+            for nm in ("norm0", "norm1") + (("norm2",) if b.attention else ()):
+                e[nm + ".g"], e[nm + ".b"] = f32(f"{n}.{nm}.weight"), f32(f"{n}.{nm}.bias")
+            e["conv0.w"], e["conv0.b"] = cw(f"{n}.conv0.weight"), f32(f"{n}.conv0.bias")
+            e["conv1.w"], e["conv1.b"] = cw(f"{n}.conv1.weight"), f32(f"{n}.conv1.bias")
+            if b.skip_conv:
+                e["skip.w"], e["skip.b"] = cw(f"{n}.skip.weight"), f32(f"{n}.skip.bias")
+            if b.attention:
+                # reference channel = head*192 + d*3 + {q,k,v} (model.py:359-363); regroup the rows so a
+                # head's q, k and v are three contiguous 64-channel blocks
+                co, heads = b.out_channels, b.num_heads
+                idx = torch.arange(3 * co, device=device).reshape(heads, 64, 3).permute(0, 2, 1).reshape(-1)
+                e["qkv.w"] = cw(f"{n}.qkv.weight")[idx].contiguous()
+                e["qkv.b"] = f32(f"{n}.qkv.bias")[idx].contiguous()
+                e["proj.w"], e["proj.b"] = cw(f"{n}.proj.weight"), f32(f"{n}.proj.bias")
+            blocks.append(e)
+        P["blocks"] = blocks
+        P["aff.w"], P["aff.b"], P["aff.total"] = torch.cat(aff_w, 0).contiguous(), torch.cat(aff_b, 0).contiguous(), off
+        P["out_norm.g"], P["out_norm.b"] = f32("out_norm.weight"), f32("out_norm.bias")
+        P["out.w"] = sd["out_conv.weight"].to(torch.float32).permute(0, 2, 3, 1).contiguous()   # fp32 (Cout,3,3,Cin)
+        P["out.b"] = f32("out_conv.bias")
+        self._packed, self._packed_key = P, key
+        return P
+
+    # ------------------------------------------------------------------ forward
+    def _block(self, e: dict, x: Tensor, skip: Optional[Tensor], ada: Tensor, ada_total: int) -> Tensor:
+        b: BlockSpec = e["spec"]
+        # norm0 + SiLU over the (virtual) concatenation, optionally 2x2-averaged for `down`
+        c0 = ops.gn_coef(x, e["norm0.g"], e["norm0.b"], gn_groups(b.in_channels), GN_EPS, x2=skip)
+        h = ops.gn_apply(x, c0, act=True, x2=skip, pool=b.down)
+        h = ops.conv2d(h, e["conv0.w"], e["conv0.b"], upsample=b.up)
+        # norm1 with AdaGN modulation + SiLU
+        c1 = ops.gn_coef(h, e["norm1.g"], e["norm1.b"], gn_groups(b.out_channels), GN_EPS,
+                         ada=ada[:, e["ada_off"]:], ada_stride=ada_total)
+        h = ops.gn_apply(h, c1, act=True)
+        if b.skip_conv:
+            res, mode = ops.conv2d(x, e["skip.w"], e["skip.b"], x2=skip), _lib.RES_SAME
+        elif b.up:
+            res, mode = x, _lib.RES_UP
+        elif b.down:
+            res, mode = x, _lib.RES_DOWN
+        else:
+            res, mode = x, _lib.RES_SAME
+        x = ops.conv2d(h, e["conv1.w"], e["conv1.b"], residual=res, res_mode=mode)
+        if b.attention:
+            c2 = ops.gn_coef(x, e["norm2.g"], e["norm2.b"], gn_groups(b.out_channels), GN_EPS)
+            h = ops.gn_apply(x, c2, act=False)
+            qkv = ops.conv2d(h, e["qkv.w"], e["qkv.b"])
+            a = ops.attention(qkv, b.num_heads)
+            x = ops.conv2d(a, e["proj.w"], e["proj.b"], residual=x, res_mode=_lib.RES_SAME)
+        return x
+
+    @torch.no_grad()
+    def forward(self, x: Tensor, noise_labels: Tensor, class_labels: Optional[Tensor] = None,
+                augment_labels=None, taps: Optional[dict] = None):
+        if not x.is_cuda:
+            raise RuntimeError("DhariwalUNet runs on HIP kernels only; move the input to the GPU")
+        s = self.spec
+        P = self._pack(x.device)
+        dt = P["dtype"]
+        B = x.shape[0]
+        if tuple(x.shape[1:]) != (s.in_channels, s.img_resolution, s.img_resolution):
+            raise ValueError(f"input shape {tuple(x.shape)} does not fit the model ({s.in_channels}, "
+                             f"{s.img_resolution}, {s.img_resolution})")
+        x = x.to(torch.float32).contiguous()
+        t = noise_labels.to(device=x.device, dtype=torch.float32).reshape(-1).contiguous()
+        if t.numel() not in (1, B):
+            raise ValueError(f"noise_labels must have 1 or {B} entries, got {t.numel()}")
+        # embedding MLP (model.py:564-576)
+        emb = ops.pos_embedding(t, P["freqs"], B)
+        emb = ops.linear_f32(emb, P["map_layer0.weight"], P["map_layer0.bias"], act_out=True)
+        if s.label_dim:
+            if class_labels is None:
+                class_labels = torch.zeros((1, s.label_dim), device=x.device)
+            lab = class_labels.to(device=x.device, dtype=torch.float32).reshape(-1, s.label_dim)
+            if lab.shape[0] == 1 and B > 1:
+                lab = lab.expand(B, -1)
+            if lab.shape[0] != B:
+                raise ValueError(f"class_labels must have 1 or {B} rows, got {lab.shape[0]}")
+            emb = ops.linear_f32(emb, P["map_layer1.weight"], P["map_layer1.bias"])
+            emb = ops.linear_f32(lab.contiguous(), P["map_label.weight"], None, out=emb, accumulate=True,
+                                 act_out=True)
+        else:
+            emb = ops.linear_f32(emb, P["map_layer1.weight"], P["map_layer1.bias"], act_out=True)
+        ada = ops.linear_f32(emb, P["aff.w"], P["aff.b"])          # every block's affine at once
+        total = P["aff.total"]
+        if taps is not None:
+            taps["emb"] = emb
+
+        h = ops.conv_in(x, P["in.w"], P["in.b"], dt)
+        skips = [h]
+        if taps is not None:
+            taps[s.enc_conv_name] = h
+        n_enc = len(s.enc)
+        for i, e in enumerate(P["blocks"]):
+            b: BlockSpec = e["spec"]
+            if i < n_enc:
+                h = self._block(e, h, None, ada, total)
+                skips.append(h)
+            else:
+                h = self._block(e, h, skips.pop() if b.cat_skip else None, ada, total)
+            if taps is not None:
+                taps[b.name] = h
+        c = ops.gn_coef(h, P["out_norm.g"], P["out_norm.b"], gn_groups(s.final_channels), GN_EPS)
+        h = ops.gn_apply(h, c, act=True)
+        return (ops.conv_out(h, P["out.w"], P["out.b"]),)
+
+
+class Denoiser(nn.Module):
+    """``model(x, t, text=..., class_labels=...) -> Tensor`` as the loops call it."""
+
+    def __init__(self, unet: DhariwalUNet):
+        super().__init__()
+        self.unet = unet
+
+    def state_dict(self, *args, **kwargs):
+        return self.unet.state_dict(*args, **kwargs)
+
+    def load_state_dict(self, state_dict, strict=True):
+        return self.unet.load_state_dict(state_dict, strict)
+
+    @property
+    def spec(self) -> UNetSpec:
+        return self.unet.spec
+
+    def forward(self, x: Tensor, time: Tensor, text=None, class_labels: Optional[Tensor] = None) -> Tensor:
+        time = torch.as_tensor(time, device=x.device).to(torch.float32).reshape(-1)
+        return self.unet(x, time, class_labels)[0]
+
+
+def build_model(cfg, precision: str = "bf16") -> Denoiser:
+    s = spec_from_cfg(cfg)
+    unet = DhariwalUNet(img_resolution=s.img_resolution, in_channels=s.in_channels,
+                        out_channels=s.out_channels, label_dim=s.label_dim, augment_dim=0,
+                        model_channels=s.model_channels, channel_mult=s.channel_mult,
+                        channel_mult_emb=4, num_blocks=s.num_blocks, dropout=0.10, label_dropout=0,
+                        eff_attn=True, precision=precision)
+    return Denoiser(unet)

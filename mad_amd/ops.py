@@ -1,0 +1,253 @@
+"""Operator-level Python wrappers over the C ABI (one function per entry point).
+
+Tensors are torch CUDA tensors used only as device memory; every wrapper checks shapes, dtype,
+contiguity and device before handing raw pointers to the library, enqueues on torch's current
+stream and returns the output tensor.  Activations are NHWC: shape (B, H, W, C).
+"""
+from __future__ import annotations
+
+from typing import Optional, Sequence
+
+import torch
+
+from . import _lib
+from ._lib import SamplerCoef, check, lib
+
+Tensor = torch.Tensor
+
+
+def _dtype_code(t: Tensor) -> int:
+    if t.dtype == torch.bfloat16:
+        return _lib.MAD_BF16
+    if t.dtype == torch.float32:
+        return _lib.MAD_F32
+    raise TypeError(f"unsupported activation dtype {t.dtype}")
+
+
+def _dev(*ts: Optional[Tensor]) -> None:
+    dev = None
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError("mad_amd operators run on the GPU only (got a CPU tensor); there is no CPU path")
+        if not t.is_contiguous():
+            raise ValueError("mad_amd operators need contiguous tensors")
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise ValueError(f"tensors on different devices: {t.device} vs {dev}")
+
+
+def _ptr(t: Optional[Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+# ------------------------------------------------------------------------------ sampler
+def sampler_update(coef: SamplerCoef, model_output: Tensor, sample: Tensor,
+                   noise: Optional[Tensor] = None, original: Optional[Tensor] = None,
+                   mask: Optional[Tensor] = None, next_sample: Optional[Tensor] = None,
+                   want_x0: bool = False):
+    _dev(model_output, sample, noise, original, mask, next_sample)
+    for t in (model_output, sample, noise, original, next_sample):
+        if t is not None and (t.dtype != torch.float32 or t.shape != sample.shape):
+            raise ValueError("sampler tensors must be fp32 and share the sample's shape")
+    B, C, H, W = sample.shape
+    mask_batch = 1
+    if mask is not None:
+        if mask.dtype != torch.float32 or mask.numel() not in (H * W, B * H * W):
+            raise ValueError(f"mask must be fp32 with H*W or B*H*W elements, got {tuple(mask.shape)}")
+        mask_batch = mask.numel() // (H * W)
+    out = torch.empty_like(sample)
+    x0 = torch.empty_like(sample) if want_x0 else None
+    check(lib.mad_sampler_update(coef, _ptr(model_output), _ptr(sample), _ptr(noise), _ptr(original),
+                                 _ptr(mask), _ptr(next_sample), _ptr(out), _ptr(x0), B, C, H, W,
+                                 mask_batch, _stream()), "mad_sampler_update")
+    return (out, x0) if want_x0 else out
+
+
+def add_noise(x0: Tensor, noise: Tensor, sa: float, sb: float, mask: Optional[Tensor] = None) -> Tensor:
+    _dev(x0, noise, mask)
+    if x0.dtype != torch.float32 or noise.dtype != torch.float32 or noise.shape != x0.shape:
+        raise ValueError("add_noise needs fp32 tensors of equal shape")
+    B, C, H, W = x0.shape
+    mask_batch = 1
+    if mask is not None:
+        if mask.dtype != torch.float32 or mask.numel() not in (H * W, B * H * W):
+            raise ValueError("mask must be fp32 with H*W or B*H*W elements")
+        mask_batch = mask.numel() // (H * W)
+    out = torch.empty_like(x0)
+    check(lib.mad_add_noise(_ptr(x0), _ptr(noise), _ptr(mask), _ptr(out), float(sa), float(sb), B, C, H, W,
+                            mask_batch, _stream()), "mad_add_noise")
+    return out
+
+
+def finalize_image(x: Tensor, normalize: bool = True) -> Tensor:
+    _dev(x)
+    if x.dtype != torch.float32:
+        raise ValueError("finalize_image needs fp32")
+    out = torch.empty_like(x)
+    check(lib.mad_finalize_image(_ptr(x), _ptr(out), int(normalize), x.numel(), _stream()), "mad_finalize_image")
+    return out
+
+
+def masked_copy_(dst: Tensor, src: Tensor, mask: Tensor) -> Tensor:
+    _dev(dst, src, mask)
+    B, C, H, W = dst.shape
+    if src.shape != dst.shape or dst.dtype != torch.float32 or src.dtype != torch.float32:
+        raise ValueError("masked_copy_ needs fp32 tensors of equal shape")
+    if mask.dtype != torch.float32 or mask.numel() not in (H * W, B * H * W):
+        raise ValueError("mask must be fp32 with H*W or B*H*W elements")
+    check(lib.mad_masked_copy(_ptr(dst), _ptr(src), _ptr(mask), B, C, H, W, mask.numel() // (H * W), _stream()),
+          "mad_masked_copy")
+    return dst
+
+
+def keep_mask(label_map: Tensor, comps: Sequence[int], dilate: bool = True) -> Tensor:
+    """label_map (H,W) uint8 on the GPU -> (1,H,W) fp32 keep-mask; comps already priority-sorted."""
+    _dev(label_map)
+    if label_map.dtype != torch.uint8 or label_map.dim() != 2:
+        raise ValueError("label_map must be a (H,W) uint8 tensor")
+    H, W = label_map.shape
+    comps_t = torch.tensor(list(comps), dtype=torch.int32, device=label_map.device)
+    out = torch.empty((1, H, W), dtype=torch.float32, device=label_map.device)
+    check(lib.mad_keep_mask(_ptr(label_map), _ptr(out), H, W, _ptr(comps_t), len(comps), int(dilate), _stream()),
+          "mad_keep_mask")
+    return out
+
+
+# ------------------------------------------------------------------------------ embedding
+def pos_embedding(t: Tensor, freqs: Tensor, rows: int) -> Tensor:
+    _dev(t, freqs)
+    if t.dtype != torch.float32 or freqs.dtype != torch.float32:
+        raise ValueError("pos_embedding needs fp32 timesteps (integer timesteps truncate the frequencies)")
+    half = freqs.numel()
+    out = torch.empty((rows, 2 * half), dtype=torch.float32, device=t.device)
+    check(lib.mad_pos_embedding(_ptr(t), t.numel(), _ptr(freqs), _ptr(out), rows, half, _stream()),
+          "mad_pos_embedding")
+    return out
+
+
+def linear_f32(x: Tensor, W: Tensor, bias: Optional[Tensor] = None, act_in: bool = False,
+               act_out: bool = False, out: Optional[Tensor] = None, accumulate: bool = False) -> Tensor:
+    _dev(x, W, bias, out)
+    rows, K = x.shape
+    N = W.shape[0]
+    if W.shape[1] != K or x.dtype != torch.float32 or W.dtype != torch.float32:
+        raise ValueError(f"linear_f32 shape/dtype mismatch: x {tuple(x.shape)} W {tuple(W.shape)}")
+    if out is None:
+        if accumulate:
+            raise ValueError("accumulate needs an output tensor")
+        out = torch.empty((rows, N), dtype=torch.float32, device=x.device)
+    check(lib.mad_linear_f32(_ptr(x), _ptr(W), _ptr(bias), _ptr(out), rows, K, N, int(act_in), int(act_out),
+                             int(accumulate), _stream()), "mad_linear_f32")
+    return out
+
+
+# ------------------------------------------------------------------------------ convolutions
+def conv_in(x: Tensor, w: Tensor, bias: Tensor, dtype: torch.dtype) -> Tensor:
+    """x NCHW fp32 -> NHWC `dtype`; w (Cout,Cin,3,3) fp32."""
+    _dev(x, w, bias)
+    B, Cin, H, W_ = x.shape
+    Cout = w.shape[0]
+    if x.dtype != torch.float32 or w.dtype != torch.float32 or tuple(w.shape) != (Cout, Cin, 3, 3):
+        raise ValueError("conv_in needs fp32 NCHW input and (Cout,Cin,3,3) fp32 weights")
+    y = torch.empty((B, H, W_, Cout), dtype=dtype, device=x.device)
+    check(lib.mad_conv_in(_ptr(x), _ptr(w), _ptr(bias), _ptr(y), _dtype_code(y), B, Cin, H, W_, Cout, _stream()),
+          "mad_conv_in")
+    return y
+
+
+def conv_out(x: Tensor, w: Tensor, bias: Tensor) -> Tensor:
+    """x NHWC -> NCHW fp32; w (Cout,3,3,Cin) fp32."""
+    _dev(x, w, bias)
+    B, H, W_, Cin = x.shape
+    Cout = w.shape[0]
+    if w.dtype != torch.float32 or tuple(w.shape) != (Cout, 3, 3, Cin):
+        raise ValueError("conv_out needs (Cout,3,3,Cin) fp32 weights")
+    y = torch.empty((B, Cout, H, W_), dtype=torch.float32, device=x.device)
+    check(lib.mad_conv_out(_ptr(x), _dtype_code(x), _ptr(w), _ptr(bias), _ptr(y), B, Cin, H, W_, Cout, _stream()),
+          "mad_conv_out")
+    return y
+
+
+def conv2d(x1: Tensor, w: Tensor, bias: Optional[Tensor], x2: Optional[Tensor] = None,
+           residual: Optional[Tensor] = None, res_mode: int = _lib.RES_NONE, upsample: bool = False) -> Tensor:
+    """Implicit-GEMM conv; x NHWC, w (Cout,k,k,C1+C2) in the activation dtype, bias fp32."""
+    _dev(x1, x2, w, bias, residual)
+    B, Hs, Ws, C1 = x1.shape
+    C2 = 0 if x2 is None else x2.shape[3]
+    H, W_ = (2 * Hs, 2 * Ws) if upsample else (Hs, Ws)
+    Cout, k = w.shape[0], w.shape[1]
+    if w.dtype != x1.dtype or tuple(w.shape) != (Cout, k, k, C1 + C2):
+        raise ValueError(f"conv2d weight {tuple(w.shape)}/{w.dtype} does not match input channels {C1}+{C2}/{x1.dtype}")
+    if x2 is not None and (x2.dtype != x1.dtype or tuple(x2.shape[:3]) != (B, Hs, Ws)):
+        raise ValueError("conv2d second input must match the first in dtype and spatial shape")
+    if bias is not None and (bias.dtype != torch.float32 or bias.numel() != Cout):
+        raise ValueError("conv2d bias must be fp32 of length Cout")
+    if residual is not None:
+        want = {_lib.RES_SAME: (B, H, W_, Cout), _lib.RES_UP: (B, H // 2, W_ // 2, Cout),
+                _lib.RES_DOWN: (B, 2 * H, 2 * W_, Cout)}.get(res_mode)
+        if want is None or tuple(residual.shape) != want or residual.dtype != x1.dtype:
+            raise ValueError(f"conv2d residual {tuple(residual.shape)} does not fit mode {res_mode} (want {want})")
+    elif res_mode != _lib.RES_NONE:
+        raise ValueError("res_mode set without a residual tensor")
+    y = torch.empty((B, H, W_, Cout), dtype=x1.dtype, device=x1.device)
+    check(lib.mad_conv2d(_ptr(x1), C1, _ptr(x2), C2, _ptr(w), _ptr(bias), _ptr(residual), res_mode, _ptr(y),
+                         _dtype_code(x1), B, H, W_, Cout, k, int(upsample), _stream()), "mad_conv2d")
+    return y
+
+
+# ------------------------------------------------------------------------------ GroupNorm
+def gn_nsplit(HW: int) -> int:
+    return min(64, max(1, HW // 64))
+
+
+def gn_coef(x1: Tensor, gamma: Tensor, beta: Tensor, groups: int, eps: float, x2: Optional[Tensor] = None,
+            ada: Optional[Tensor] = None, ada_stride: int = 0) -> Tensor:
+    """Statistics + folding: returns coef (B, C, 2) with y = x*a + d.  `ada` is a view whose
+    data pointer is the first scale element of sample 0; rows are `ada_stride` floats apart."""
+    _dev(x1, x2, gamma, beta)
+    B, H, W_, C1 = x1.shape
+    C2 = 0 if x2 is None else x2.shape[3]
+    C = C1 + C2
+    HW = H * W_
+    nsplit = gn_nsplit(HW)
+    partial = torch.empty((B, nsplit, C, 2), dtype=torch.float32, device=x1.device)
+    check(lib.mad_gn_partial(_ptr(x1), C1, _ptr(x2), C2, _dtype_code(x1), _ptr(partial), B, HW, nsplit, _stream()),
+          "mad_gn_partial")
+    coef = torch.empty((B, C, 2), dtype=torch.float32, device=x1.device)
+    if gamma.numel() != C or beta.numel() != C:
+        raise ValueError("GroupNorm gain/offset length does not match the channel count")
+    check(lib.mad_gn_finalize(_ptr(partial), _ptr(gamma), _ptr(beta), None if ada is None else ada.data_ptr(),
+                              ada_stride, _ptr(coef), B, C, groups, HW, nsplit, float(eps), _stream()),
+          "mad_gn_finalize")
+    return coef
+
+
+def gn_apply(x1: Tensor, coef: Tensor, act: bool, x2: Optional[Tensor] = None, pool: bool = False) -> Tensor:
+    _dev(x1, x2, coef)
+    B, H, W_, C1 = x1.shape
+    C2 = 0 if x2 is None else x2.shape[3]
+    Ho, Wo = (H // 2, W_ // 2) if pool else (H, W_)
+    y = torch.empty((B, Ho, Wo, C1 + C2), dtype=x1.dtype, device=x1.device)
+    check(lib.mad_gn_apply(_ptr(x1), C1, _ptr(x2), C2, _ptr(coef), _ptr(y), _dtype_code(x1), B, H, W_, int(act),
+                           int(pool), _stream()), "mad_gn_apply")
+    return y
+
+
+# ------------------------------------------------------------------------------ attention
+def attention(qkv: Tensor, heads: int) -> Tensor:
+    """qkv (B,H,W,3C) with per-head [q|k|v] channel blocks -> (B,H,W,C)."""
+    _dev(qkv)
+    B, H, W_, C3 = qkv.shape
+    C = C3 // 3
+    if C != heads * 64:
+        raise ValueError(f"attention needs head_dim 64: C={C}, heads={heads}")
+    out = torch.empty((B, H, W_, C), dtype=qkv.dtype, device=qkv.device)
+    check(lib.mad_attention(_ptr(qkv), _ptr(out), _dtype_code(qkv), B, H * W_, heads, _stream()), "mad_attention")
+    return out

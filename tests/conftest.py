@@ -29,3 +29,14 @@ def rel_err(a, b):
     a = torch.as_tensor(a, dtype=torch.float64)
     b = torch.as_tensor(b, dtype=torch.float64)
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def _ensure_built():
+    """The HIP library is a build artefact (not in git): compile it when a fresh tree lacks it."""
+    so = os.path.join(REPO, "mad_amd", "libmad_hip.so")
+    if not os.path.exists(so):
+        import subprocess
+        subprocess.run(["make", "-C", os.path.join(REPO, "mad_amd", "csrc"), "-j8"], check=True)
+
+
+_ensure_built()

@@ -1,0 +1,270 @@
+"""Kernel-level parity: each C-ABI entry point against the CPU oracle / golden vectors (GPU only)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import load_golden, rel_err
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch.device("cuda:0")
+
+
+def _rand(shape, seed, scale=1.0):
+    return torch.randn(shape, generator=torch.Generator().manual_seed(seed)) * scale
+
+
+def _nhwc(x, dt, dev):
+    return x.permute(0, 2, 3, 1).contiguous().to(dt).to(dev)
+
+
+def _nchw(y):
+    return y.float().cpu().permute(0, 3, 1, 2)
+
+
+# ------------------------------------------------------------------------------ sampler
+@pytest.mark.parametrize("kind", ["ddpm", "ddim"])
+def test_sampler_golden(dev, kind):
+    """Every sampler golden (t in {0,1,179,699,999}, 1000- and 50-step tables, masked / clipped /
+    compute_eps / inversion / add_noise).  Bit-exact is expected; 2 ulp-ish slack is allowed."""
+    from mad_amd.scheduler import SCHEDULER_FUNC
+    g = load_golden("sampler.npz")
+    s = SCHEDULER_FUNC[kind]()
+    np.testing.assert_array_equal(s.alphas_cumprod.numpy(), g[f"{kind}/alphas_cumprod"])
+    n_exact = n_total = 0
+
+    def cmp(got, key):
+        nonlocal n_exact, n_total
+        want = torch.from_numpy(g[key])
+        got = got.cpu()
+        n_total += 1
+        n_exact += int(torch.equal(got, want))
+        scale = float(want.abs().max())
+        assert float((got - want).abs().max()) <= 4e-7 * max(scale, 1.0), key
+
+    for n in (1000, 50):
+        s.set_timesteps(n)
+        np.testing.assert_array_equal(s.timesteps.numpy(), g[f"{kind}/timesteps_{n}"])
+        s.set_inverse_timesteps(n)
+        np.testing.assert_array_equal(s.timesteps.numpy(), g[f"{kind}/inverse_timesteps_{n}"])
+        s.set_timesteps(n)
+        ratio = 1000 // n
+        for t in sorted({(t // ratio) * ratio for t in (0, 1, 179, 699, 999)}):
+            key = f"{kind}/n{n}/t{t}"
+            T = lambda nm: torch.from_numpy(g[f"{key}/{nm}"]).to(dev)
+            for pt in ("epsilon", "sample"):
+                s.config.prediction_type = pt
+                r = s.step(T("eps"), t, T("sample"), eta=0.01, variance_noise=T("noise"), return_pred_original=True)
+                cmp(r.prev_sample, f"{key}/{pt}/step")
+                cmp(r.pred_original_sample, f"{key}/{pt}/x0")
+                r = s.step(T("eps"), t, T("sample"), eta=0.01, variance_noise=T("noise"), original_image=T("orig"),
+                           mask=T("mask"))
+                cmp(r.prev_sample, f"{key}/{pt}/step_masked")
+                if kind == "ddim":
+                    r = s.step(T("eps"), t, T("sample"), eta=1.0, variance_noise=T("noise"),
+                               use_clipped_model_output=True)
+                    cmp(r.prev_sample, f"{key}/{pt}/step_eta1_clipped")
+                if t > 0:
+                    cmp(s.compute_eps(T("eps"), t, T("sample"), T("next"), eta=0.01), f"{key}/{pt}/compute_eps")
+                cmp(s.ddim_inverse_step(T("eps"), t, T("sample")).prev_sample, f"{key}/{pt}/inverse")
+            s.config.prediction_type = "epsilon"
+            cmp(s.add_noise(T("orig"), T("noise"), torch.tensor([t])), f"{key}/add_noise")
+    print(f"{kind}: {n_exact}/{n_total} sampler goldens bit-exact")
+    assert n_exact >= 0.9 * n_total
+
+
+def test_sampler_errors(dev):
+    from mad_amd.scheduler import CustomDDIMScheduler, CustomDDPMScheduler
+    z = torch.zeros(1, 3, 4, 4, device=dev)
+    d = CustomDDIMScheduler()
+    with pytest.raises(ValueError):
+        d.step(z, 10, z)
+    p = CustomDDPMScheduler()
+    p.set_timesteps(1000)
+    with pytest.raises(AssertionError):
+        p.compute_eps(z, 0, z, z)
+    p.config.prediction_type = "bogus"
+    with pytest.raises(ValueError):
+        p.step(z, 10, z)
+    with pytest.raises(RuntimeError):
+        from mad_amd import ops
+        ops.add_noise(torch.zeros(1, 3, 4, 4), torch.zeros(1, 3, 4, 4), 1.0, 0.0)   # CPU tensor: no CPU path
+
+
+def test_masked_batch_and_finalize(dev):
+    from mad_amd import ops
+    from mad_amd.scheduler import CustomDDPMScheduler
+    from oracle.scheduler_ref import RefScheduler
+    s, r = CustomDDPMScheduler(), RefScheduler("ddpm")
+    s.set_timesteps(1000); r.set_timesteps(1000)
+    B = 3
+    eps, x, z, o = (_rand((B, 3, 16, 16), i) for i in range(4))
+    mask = (_rand((B, 1, 16, 16), 9) > 0).float()
+    got = s.step(eps.to(dev), 500, x.to(dev), variance_noise=z.to(dev), original_image=o.to(dev), mask=mask.to(dev))
+    want = r.step(eps, 500, x, variance_noise=z, original_image=o, mask=mask)
+    assert float((got.prev_sample.cpu() - want.prev_sample).abs().max()) < 1e-6
+    y = ops.finalize_image((x * 2).to(dev), True).cpu()
+    assert torch.equal(y, (x * 2).clamp(-1, 1) / 2 + 0.5)
+    dst = x.clone().to(dev)
+    ops.masked_copy_(dst, o.to(dev), mask.to(dev))
+    assert torch.equal(dst.cpu(), torch.where(mask.expand(-1, 3, -1, -1) > 0, o, x))
+
+
+def test_keep_mask_golden(dev):
+    from mad_amd import ops
+    from mad_amd.translation import COMP_PRIORITY, TranslationDiffusion
+    g = load_golden("masks.npz")
+    lab = torch.from_numpy(g["label_map"]).to(torch.uint8).to(dev)
+    basic = sorted(TranslationDiffusion.BASIC_COMPONENT, key=lambda c: COMP_PRIORITY[c])
+    assert torch.equal(ops.keep_mask(lab, basic, True).cpu(), torch.from_numpy(g["keep_all"]))
+    assert torch.equal(ops.keep_mask(lab, basic, False).cpu(), torch.from_numpy(g["keep_nodilate"]))
+    for k in g.files:
+        if k.startswith("keep_") and k[5].isdigit():
+            comps = sorted([int(c) for c in k[5:].split("_")], key=lambda c: COMP_PRIORITY[c])
+            assert torch.equal(ops.keep_mask(lab, comps, True).cpu(), torch.from_numpy(g[k])), k
+
+
+# ------------------------------------------------------------------------------ embedding
+def test_embedding_and_linear(dev):
+    from mad_amd import ops
+    from oracle.unet_ref import positional_embedding
+    t = torch.tensor([0.0, 1.0, 333.0, 999.0])
+    half = 96
+    freqs = (1.0 / 10000) ** (torch.arange(half, dtype=torch.float32) / half)
+    got = ops.pos_embedding(t.to(dev), freqs.to(dev), 4).cpu()
+    want = positional_embedding(t, 2 * half)
+    assert float((got - want).abs().max()) < 2e-5        # sin/cos of arguments up to ~1000 rad
+    got1 = ops.pos_embedding(t[2:3].to(dev), freqs.to(dev), 4).cpu()       # one timestep broadcast
+    assert torch.equal(got1[0], got1[3]) and torch.equal(got1[0], got[2])
+    x, W, b = _rand((5, 192), 1), _rand((300, 192), 2, 0.1), _rand((300,), 3)
+    y = ops.linear_f32(x.to(dev), W.to(dev), b.to(dev), act_out=True)
+    assert rel_err(y.cpu(), F.silu(x @ W.t() + b)) < 1e-5
+    y2 = ops.linear_f32(x.to(dev), W.to(dev), None, out=y.clone(), accumulate=True, act_in=True)
+    assert rel_err(y2.cpu(), F.silu(x @ W.t() + b) + F.silu(x) @ W.t()) < 1e-5
+
+
+# ------------------------------------------------------------------------------ convolutions
+CONV_CASES = [
+    # B, H, C1, C2, Cout, k, up, res
+    (2, 8, 64, 0, 64, 3, False, "none"),
+    (3, 8, 128, 0, 128, 3, False, "same"),      # M = 192: partial last tile
+    (1, 16, 64, 64, 192, 3, False, "none"),     # concat of two sources, 64-wide n tiles
+    (2, 16, 128, 0, 128, 3, True, "up"),        # nearest x2 in the loader and on the residual
+    (2, 16, 64, 0, 128, 3, False, "down"),      # 2x2-mean residual
+    (2, 8, 128, 64, 256, 1, False, "none"),     # 1x1 over a concat
+    (1, 32, 192, 0, 576, 1, False, "same"),
+    (2, 64, 128, 0, 128, 3, False, "same"),     # several tiles, several rows per tile
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_conv2d(dev, case, dt):
+    from mad_amd import _lib, ops
+    B, H, C1, C2, Cout, k, up, res = case
+    Hs = H // 2 if up else H
+    x1 = _rand((B, C1, Hs, Hs), 1)
+    x2 = _rand((B, C2, Hs, Hs), 2) if C2 else None
+    w = _rand((Cout, C1 + C2, k, k), 3, 1.0 / math.sqrt((C1 + C2) * k * k))
+    b = _rand((Cout,), 4)
+    rshape = {"none": None, "same": (B, Cout, H, H), "up": (B, Cout, H // 2, H // 2), "down": (B, Cout, 2 * H, 2 * H)}[res]
+    r = _rand(rshape, 5) if rshape else None
+    q = (lambda t: t.to(dt).float()) if dt == torch.bfloat16 else (lambda t: t)
+    xin = q(x1) if x2 is None else torch.cat([q(x1), q(x2)], 1)
+    if up:
+        xin = xin.repeat_interleave(2, 2).repeat_interleave(2, 3)
+    want = F.conv2d(xin.double(), q(w).double(), b.double(), padding=k // 2)
+    if res == "same":
+        want = want + q(r).double()
+    elif res == "up":
+        want = want + q(r).double().repeat_interleave(2, 2).repeat_interleave(2, 3)
+    elif res == "down":
+        want = want + F.avg_pool2d(q(r).double(), 2)
+    mode = {"none": _lib.RES_NONE, "same": _lib.RES_SAME, "up": _lib.RES_UP, "down": _lib.RES_DOWN}[res]
+    y = ops.conv2d(_nhwc(x1, dt, dev), w.permute(0, 2, 3, 1).contiguous().to(dt).to(dev), b.to(dev),
+                   x2=None if x2 is None else _nhwc(x2, dt, dev),
+                   residual=None if r is None else _nhwc(r, dt, dev), res_mode=mode, upsample=up)
+    assert tuple(y.shape) == (B, H, H, Cout)
+    tol = 2e-5 if dt == torch.float32 else 6e-3       # bf16: inputs are pre-rounded, only the output rounds
+    assert rel_err(_nchw(y), want) < tol
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_conv_in_out(dev, dt):
+    from mad_amd import ops
+    x = _rand((2, 3, 16, 16), 1)
+    w, b = _rand((64, 3, 3, 3), 2, 0.2), _rand((64,), 3)
+    y = ops.conv_in(x.to(dev), w.to(dev), b.to(dev), dt)
+    assert rel_err(_nchw(y), F.conv2d(x, w, b, padding=1)) < (1e-5 if dt == torch.float32 else 6e-3)
+    h = _rand((2, 64, 16, 16), 4)
+    wo, bo = _rand((3, 64, 3, 3), 5, 0.05), _rand((3,), 6)
+    hq = h.to(dt).float()
+    yo = ops.conv_out(_nhwc(h, dt, dev), wo.permute(0, 2, 3, 1).contiguous().to(dev), bo.to(dev))
+    assert rel_err(yo.cpu(), F.conv2d(hq, wo, bo, padding=1)) < 1e-5
+
+
+# ------------------------------------------------------------------------------ GroupNorm
+GN_CASES = [
+    # B, H, C1, C2, ada, act, pool
+    (2, 16, 64, 0, False, True, False),        # 16 groups of 4
+    (2, 16, 128, 64, False, True, False),      # 192 channels, groups of 6 straddle the two sources
+    (3, 8, 256, 0, True, True, False),         # AdaGN modulation
+    (2, 16, 128, 0, False, True, True),        # fused 2x2 mean (encoder downsample)
+    (1, 32, 512, 256, False, False, False),    # no activation (norm2), 24 channels per group
+    (2, 8, 1536, 0, True, True, False),        # widest layer of the 64x64 model
+]
+
+
+@pytest.mark.parametrize("case", GN_CASES)
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_groupnorm(dev, case, dt):
+    from mad_amd import ops
+    B, H, C1, C2, use_ada, act, pool = case
+    C = C1 + C2
+    x1, x2 = _rand((B, C1, H, H), 1, 1.5) + 0.3, (_rand((B, C2, H, H), 2, 0.7) - 0.2 if C2 else None)
+    gamma, beta = 1 + 0.2 * _rand((C,), 3), 0.2 * _rand((C,), 4)
+    groups = min(32, C // 4)
+    q = (lambda t: t.to(dt).float()) if dt == torch.bfloat16 else (lambda t: t)
+    xin = q(x1) if x2 is None else torch.cat([q(x1), q(x2)], 1)
+    want = F.group_norm(xin.double(), groups, gamma.double(), beta.double(), 1e-5)
+    ada = None
+    if use_ada:
+        ada_full = _rand((B, 7 + 2 * C), 5, 0.3)             # an offset view into a wider table
+        scale, shift = ada_full[:, 7:7 + C], ada_full[:, 7 + C:]
+        want = shift.double()[:, :, None, None] + want * (scale.double()[:, :, None, None] + 1)
+        ada_dev = ada_full.to(dev)
+        ada = ada_dev[:, 7:]
+    if act:
+        want = F.silu(want)
+    if pool:
+        want = F.avg_pool2d(want, 2)
+    a1 = _nhwc(x1, dt, dev)
+    a2 = None if x2 is None else _nhwc(x2, dt, dev)
+    coef = ops.gn_coef(a1, gamma.to(dev), beta.to(dev), groups, 1e-5, x2=a2, ada=ada,
+                       ada_stride=(7 + 2 * C) if use_ada else 0)
+    y = ops.gn_apply(a1, coef, act=act, x2=a2, pool=pool)
+    assert rel_err(_nchw(y), want) < (2e-5 if dt == torch.float32 else 6e-3)
+
+
+# ------------------------------------------------------------------------------ attention
+@pytest.mark.parametrize("B,L,heads", [(2, 64, 1), (1, 256, 2), (2, 1024, 4), (3, 64, 12)])
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_attention(dev, B, L, heads, dt):
+    from mad_amd import ops
+    side = int(math.isqrt(L))
+    q, k, v = (_rand((B, heads, L, 64), s, 1.3) for s in (1, 2, 3))
+    k[0, 0, 5] *= 6.0                                        # one dominant key: forces max rescaling mid-loop
+    qq = (lambda t: t.to(dt).float()) if dt == torch.bfloat16 else (lambda t: t)
+    w = torch.softmax(qq(q).double() @ qq(k).double().transpose(-1, -2) / 8.0, dim=-1)
+    want = (w @ qq(v).double()).permute(0, 2, 1, 3).reshape(B, L, heads * 64)
+    qkv = torch.cat([q, k, v], dim=-1).permute(0, 2, 1, 3).reshape(B, side, side, heads * 192)
+    out = ops.attention(qkv.contiguous().to(dt).to(dev), heads)
+    assert rel_err(out.float().cpu().reshape(B, L, heads * 64), want) < (2e-5 if dt == torch.float32 else 1.2e-2)

@@ -1,0 +1,167 @@
+"""Whole-denoiser and loop parity on the GPU against golden vectors from the reference."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import REPO, load_golden, rel_err
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _model(cfg_file, precision, seed, dev):
+    from mad_amd.config import load_cfg
+    from mad_amd.model import build_model
+    cfg = load_cfg(os.path.join(REPO, "configs", cfg_file))
+    m = build_model(cfg, precision=precision)
+    m.unet.init_seeded(seed)
+    return cfg, m.to(dev).eval()
+
+
+def psnr(a, b, peak=2.0):
+    mse = float(((a.double() - b.double()) ** 2).mean())
+    return 10 * np.log10(peak * peak / max(mse, 1e-30))
+
+
+@pytest.mark.parametrize("tag,cfg_file", [("tiny", "model_tiny.yaml"), ("64", "model_64_64.yaml"),
+                                          ("256", "model_256_256.yaml")])
+def test_unet_fp32_matches_reference(dev, tag, cfg_file):
+    """fp32 mode: denoiser output within 1e-4 relative error of the reference's output."""
+    g = load_golden(f"unet_{tag}.npz")
+    cfg, m = _model(cfg_file, "fp32", int(g["seed"]), dev)
+    x, t, lab = (torch.from_numpy(g[k]).to(dev) for k in ("x", "t", "labels"))
+    taps = {}
+    y = m.unet(x, t, lab, taps=taps)[0]
+    for k in g.files:
+        if k.startswith("tap:"):
+            got = taps[k[4:]].float().cpu().permute(0, 3, 1, 2)
+            assert rel_err(got, g[k]) < 1e-4, k
+    err = rel_err(y.cpu(), g["y"])
+    print(f"unet_{tag} fp32 rel err {err:.3e}")
+    assert err < 1e-4
+    if "y_per_sample" in g.files:
+        y2 = m(x, torch.from_numpy(g["t_per_sample"]).to(dev), class_labels=lab)
+        assert rel_err(y2.cpu(), g["y_per_sample"]) < 1e-4
+        # integer timesteps are cast to float by the adapter
+        y3 = m(x, torch.tensor([333], device=dev), text=None, class_labels=lab)
+        assert rel_err(y3.cpu(), g["y"]) < 1e-4
+
+
+@pytest.mark.parametrize("tag,cfg_file", [("tiny", "model_tiny.yaml"), ("64", "model_64_64.yaml"),
+                                          ("256", "model_256_256.yaml")])
+def test_unet_bf16_close_to_reference(dev, tag, cfg_file):
+    """bf16 mode (bf16 storage + MFMA, fp32 accumulate/statistics/softmax): stated tolerance
+    PSNR >= 40 dB of the denoiser output against the reference fp32 output (peak-to-peak 2)."""
+    g = load_golden(f"unet_{tag}.npz")
+    cfg, m = _model(cfg_file, "bf16", int(g["seed"]), dev)
+    x, t, lab = (torch.from_numpy(g[k]).to(dev) for k in ("x", "t", "labels"))
+    y = m(x, t, class_labels=lab).cpu()
+    ref = torch.from_numpy(g["y"])
+    p, e = psnr(y, ref), rel_err(y, ref)
+    print(f"unet_{tag} bf16: PSNR {p:.1f} dB, rel err {e:.3e}")
+    assert p >= 40.0
+    assert e < 5e-2
+
+
+def test_state_dict_names_and_batch_independence(dev):
+    cfg, m = _model("model_tiny.yaml", "fp32", 3, dev)
+    from mad_amd.init import seeded_state_dict
+    want = seeded_state_dict(m.spec, 3)
+    sd = m.state_dict()
+    assert sorted(sd.keys()) == sorted(want.keys())
+    x = torch.randn(4, 3, 16, 16, device=dev)
+    lab = torch.eye(2, device=dev)[[0, 1, 1, 0]]
+    t = torch.tensor([100.0], device=dev)
+    y = m(x, t, class_labels=lab)
+    y1 = m(x[2:3].contiguous(), t, class_labels=lab[2:3].contiguous())
+    assert rel_err(y[2:3].cpu(), y1.cpu()) < 1e-5          # every op on the path is per-sample
+    with pytest.raises(ValueError):
+        m(torch.randn(1, 3, 8, 8, device=dev), t, class_labels=lab[:1])
+    with pytest.raises(RuntimeError):
+        m(torch.randn(1, 3, 16, 16), t.cpu(), class_labels=lab[:1].cpu())   # no CPU path
+
+
+@pytest.mark.parametrize("kind", ["ddpm", "ddim"])
+def test_trajectory_matches_reference(dev, kind):
+    """encode -> generate with a tiny denoiser in fp32 mode, replaying the reference's random draws."""
+    from mad_amd.config import load_cfg
+    from mad_amd.translation import TranslationDiffusion
+    g = load_golden("trajectory.npz")
+    steps, start = int(g[f"{kind}/sample_steps"]), int(g[f"{kind}/start"])
+    cfg, m = _model("model_tiny.yaml", "fp32", 1, dev)
+    cfg.EVAL.SCHEDULER, cfg.EVAL.SAMPLE_STEPS, cfg.EVAL.ETA = kind, steps, 0.01
+    td = TranslationDiffusion(cfg, dev)
+    draws = iter(torch.from_numpy(np.concatenate([g[f"{kind}/enc_draws"], g[f"{kind}/gen_draws"]])))
+    td.noise_source = lambda shape: next(draws)
+    image = torch.from_numpy(g[f"{kind}/image"]).to(dev)
+    src, tgt = td.process_label(0, 2), td.process_label(1, 2)
+    eps_list = td.encode(image, src, m, start_from_step=start)
+    ref_eps = torch.from_numpy(g[f"{kind}/eps_list"])
+    assert tuple(eps_list.shape) == tuple(ref_eps.shape)
+    worst = max(rel_err(eps_list[:, i].cpu(), ref_eps[:, i]) for i in range(ref_eps.shape[1]))
+    print(f"{kind}: worst per-step relative error of the encoded noise {worst:.3e}")
+    assert worst < 2e-2          # compute_eps divides by sigma_t (1e-4 .. 1e-2): denoiser error is amplified
+    ref_eps_dev = ref_eps.to(dev)
+    out = td.generate(m, eps_list=ref_eps_dev, class_label=src, source_image=image.clone(), start_from_step=start)
+    assert float((out - torch.from_numpy(g[f"{kind}/out_same_label"])).abs().max()) < 5e-4
+    mask = torch.from_numpy(g[f"{kind}/mask"]).to(dev)
+    out = td.generate(m, eps_list=ref_eps_dev, class_label=tgt, source_image=image.clone(), source_mask=mask,
+                      start_from_step=start)
+    assert float((out - torch.from_numpy(g[f"{kind}/out_target_masked"])).abs().max()) < 5e-4
+
+
+@pytest.mark.parametrize("kind,steps,start", [("ddpm", 1000, 12), ("ddim", 50, -1)])
+def test_replay_invariant(dev, kind, steps, start):
+    """With the label unchanged, generate(eps_list=encode(...)) retraces the encoded trajectory: the
+    replayed x_{t-1} equals the encode-side x_{t-1} at every replayed step."""
+    from mad_amd.translation import TranslationDiffusion
+    cfg, m = _model("model_tiny.yaml", "fp32", 1, dev)
+    cfg.EVAL.SCHEDULER, cfg.EVAL.SAMPLE_STEPS = kind, steps
+    td = TranslationDiffusion(cfg, dev)
+    td.generator = torch.Generator(device=dev).manual_seed(5)
+    image = (torch.randn(2, 3, 16, 16, device=dev) * 0.4).clamp(-0.9, 0.9)
+    src = td.process_label(0, 2)
+    enc_trace, gen_trace = [], []
+    orig_step = td.scheduler.step
+
+    def spy(*a, **k):
+        r = orig_step(*a, **k)
+        (enc_trace if td.scheduler.config.prediction_type == "sample" else gen_trace).append(r.prev_sample)
+        return r
+
+    td.scheduler.step = spy
+    eps_list = td.encode(image, src, m, start_from_step=start)
+    S = steps if start == -1 else start
+    assert tuple(eps_list.shape) == (2, S, 3, 16, 16)
+    td.generate(m, eps_list=eps_list, class_label=src, source_image=image, start_from_step=start)
+    assert len(enc_trace) == S - 1 and len(gen_trace) == S
+    worst = max(float((a - b).abs().max()) for a, b in zip(enc_trace, gen_trace))
+    print(f"{kind}: replay max abs diff {worst:.3e}")
+    assert worst < 2e-5
+
+
+def test_transfer_loop_runs_with_component_masks(dev):
+    """image_translation with inpainting + per-step component activation on a synthetic label map."""
+    from mad_amd.translation import TranslationDiffusion
+    cfg, m = _model("model_tiny.yaml", "bf16", 1, dev)
+    td = TranslationDiffusion(cfg, dev)
+    td.generator = torch.Generator(device=dev).manual_seed(7)
+    g = load_golden("masks.npz")
+    lab = torch.from_numpy(g["label_map"])[:16 * 4:4, :16 * 4:4].contiguous().to(torch.uint8)    # 16x16 map
+    src = (torch.randn(1, 3, 16, 16, device=dev) * 0.3).clamp(-1, 1)
+    guide = (torch.randn(1, 3, 16, 16, device=dev) * 0.3).clamp(-1, 1)
+    out = td.image_translation(m, m, src, src, 0, 1, source_parsing_mask=lab, use_cam=True, inpainting=True,
+                               inverse_image=guide,
+                               comp_weight_step={4: (0.4, 12), 9: (0.8, 6), 1: (0.8, 8)})
+    assert tuple(out.shape) == (1, 3, 16, 16) and not out.is_cuda
+    assert float(out.min()) >= 0.0 and float(out.max()) <= 1.0 and torch.isfinite(out).all()
+    with pytest.raises(NotImplementedError):
+        td.image_translation(m, m, src, src, 0, 1)

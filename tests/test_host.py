@@ -1,0 +1,109 @@
+"""Host-side logic and the C-ABI surface, no GPU needed."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import REPO
+from mad_amd.config import create_cfg, load_cfg
+from mad_amd.shard import shard_bounds, shard_list
+from mad_amd.unet_spec import spec_from_cfg
+
+
+def test_library_exports_every_declared_symbol():
+    import ctypes
+    from mad_amd import _lib
+    header = open(os.path.join(REPO, "include", "mad_hip.h")).read()
+    declared = set(re.findall(r"\b(mad_[a-z0-9_]+)\s*\(", header))
+    declared.discard("mad_sampler_coef")
+    assert declared, "no declarations found"
+    assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
+    so = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(so, name), name
+    assert _lib.lib.mad_version() >= 1
+    # struct layout agrees with the header: 7 int32 + 10 float
+    assert ctypes.sizeof(_lib.SamplerCoef) == 17 * 4
+
+
+def test_rejections_happen_before_launch():
+    """Bad arguments are refused with a message and nothing is launched (no GPU is touched)."""
+    from mad_amd._lib import SamplerCoef, lib
+    assert lib.mad_conv2d(None, 64, None, 0, None, None, None, 0, None, 0, 1, 8, 8, 64, 3, 0, None) != 0
+    assert b"null pointer" in lib.mad_last_error()
+    assert lib.mad_conv2d(1, 60, None, 0, 1, None, None, 0, 1, 0, 1, 8, 8, 64, 3, 0, None) != 0
+    assert b"multiples of 64" in lib.mad_last_error()
+    assert lib.mad_attention(1, 1, 0, 1, 48, 1, None) != 0
+    assert lib.mad_gn_partial(1, 64, None, 0, 0, 1, 1, 100, 3, None) != 0
+    c = SamplerCoef()
+    c.op = 7
+    assert lib.mad_sampler_update(c, 1, 1, None, None, None, None, 1, None, 1, 3, 4, 4, 1, None) != 0
+
+
+def test_ops_refuse_cpu_tensors():
+    from mad_amd import ops
+    with pytest.raises(RuntimeError, match="GPU only"):
+        ops.finalize_image(torch.zeros(4))
+    with pytest.raises(RuntimeError, match="GPU only"):
+        ops.conv2d(torch.zeros(1, 8, 8, 64), torch.zeros(64, 3, 3, 64), None)
+
+
+def test_config_inheritance_and_overrides():
+    cfg = load_cfg(os.path.join(REPO, "configs", "model_64_64.yaml"),
+                   ["EVAL.SCHEDULER", "ddim", "EVAL.SAMPLE_STEPS", "50", "MODEL.LAYER_SCALE", "[1,2]"])
+    assert cfg.TRAIN.IMAGE_SIZE == 64 and cfg.MODEL.BASE_DIM == 192 and cfg.TRAIN.MIXED_PRECISION == "fp16"
+    assert cfg.EVAL.SCHEDULER == "ddim" and cfg.EVAL.SAMPLE_STEPS == 50 and cfg.MODEL.LAYER_SCALE == [1, 2]
+    d = create_cfg()
+    assert d.EVAL.ETA == 0.01 and d.EVAL.SCHEDULER == "ddpm" and d.MODEL.LAYER_SCALE == [1, 1, 2, 2, 4, 4]
+    with pytest.raises(KeyError):
+        load_cfg(None, ["MODEL.NOPE", "1"])
+
+
+def test_spec_matches_survey_numbers():
+    s64 = spec_from_cfg(load_cfg(os.path.join(REPO, "configs", "model_64_64.yaml")))
+    s256 = spec_from_cfg(load_cfg(os.path.join(REPO, "configs", "model_256_256.yaml")))
+    assert s64.num_params() == 295_132_803 and s256.num_params() == 138_287_491
+    assert abs(s64.flops_per_image()["total"] / 1e9 - 219.3) < 0.1
+    assert abs(s256.flops_per_image()["total"] / 1e9 - 563.2) < 0.1
+    assert sum(b.attention for b in s256.blocks()) == 16 and sum(b.attention for b in s64.blocks()) == 22
+
+
+def test_scheduler_scalars_match_fp32_torch_evaluation():
+    """The host-side coefficients equal the reference's 0-dim fp32 tensor arithmetic bit for bit."""
+    from mad_amd.scheduler import CustomDDIMScheduler, CustomDDPMScheduler
+    from oracle.scheduler_ref import RefScheduler
+    p, r = CustomDDPMScheduler(), RefScheduler("ddpm")
+    for n in (1000, 50):
+        p.set_timesteps(n); r.set_timesteps(n)
+        assert p.timesteps.tolist() == r.timesteps.tolist()
+        for t in p.timesteps.tolist():
+            c = p._coef(t, 0)
+            a_t, a_p = r._acp(t), r._acp(r._prev_t(t))
+            cur_a = a_t / a_p
+            assert np.float32(c.c0) == ((a_p ** 0.5 * (1 - cur_a)) / (1 - a_t)).numpy()
+            assert np.float32(c.c1) == (cur_a ** 0.5 * (1 - a_p) / (1 - a_t)).numpy()
+            assert np.float32(c.std) == (r.variance(t) ** 0.5).numpy()
+            assert np.float32(c.sqrt_b_t) == ((1 - a_t) ** 0.5).numpy()
+    d, rd = CustomDDIMScheduler(), RefScheduler("ddim")
+    d.set_timesteps(50); rd.set_timesteps(50)
+    for t in d.timesteps.tolist():
+        c = d._coef(t, 0, 0.01)
+        std = 0.01 * rd.variance(t) ** 0.5
+        assert np.float32(c.std) == std.numpy()
+        assert np.float32(c.dir_coef) == ((1 - rd._acp(rd._prev_t(t)) - std ** 2) ** 0.5).numpy()
+    d.set_inverse_timesteps(50)
+    assert d.timesteps.tolist() == list(range(0, 1000, 20))
+    with pytest.raises(ValueError):
+        d.set_timesteps(2000)
+
+
+def test_shard_split_follows_reference():
+    items = list(range(10))
+    got = [shard_list(items, 4, r) for r in range(4)]
+    assert [g[0] for g in got] == [[0, 1], [2, 3], [4, 5], [6, 7, 8, 9]]
+    assert [g[1] for g in got] == [0, 2, 4, 6]
+    assert shard_bounds(3, 8, 7) == (0, 3) and shard_bounds(3, 8, 0) == (0, 0)
+    with pytest.raises(ValueError):
+        shard_bounds(3, 2, 2)
