@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""Headline benchmark: translated images/sec at 256x256 for the makeup-removal loop
+(noise encoding + regeneration, DDPM, 1000-step table, --num-of-step steps each way) on the HIP path.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one full `domain_translation` of a batch of --batch synthetic faces per GPU
+(2*S-1 denoiser evaluations plus the sampler updates).  Rank 0 prints ONE JSON line.  Each rank
+processes its own batch (independent images, no data-path collective): weak scaling.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+PEAK_BF16_TFLOPS = 2500.0          # MI355X dense bf16 MFMA peak
+
+
+def parse_args():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=1)
+    p.add_argument("--warmup", type=int, default=1)
+    p.add_argument("--config", default=os.path.join(REPO, "configs", "model_256_256.yaml"))
+    p.add_argument("--batch", type=int, default=32, help="images per GPU per step")
+    p.add_argument("--num-of-step", type=int, default=700,
+                   help="start_from_step of the removal loop (reference default 700)")
+    p.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-evals", type=int, default=6, help="denoiser evaluations in the CPU sample")
+    p.add_argument("--profile-every", type=int, default=100,
+                   help="bracket the MFMA kernels of every n-th denoiser evaluation with stream events")
+    return p.parse_args()
+
+
+def cpu_baseline(cfg, spec, num_of_step, n_evals):
+    """The oracle (fp32 PyTorch-CPU restatement of the same loop) on this host's cores, on a bounded
+    sample: B=1, a removal loop shortened to ~n_evals denoiser evaluations, scaled per evaluation."""
+    from mad_amd.init import seeded_state_dict
+    from mad_amd.synthetic import synthetic_faces
+    from oracle.scheduler_ref import RefScheduler
+    from oracle.translation_ref import RefTranslation
+    from oracle.unet_ref import unet_forward
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = min(cores, int(os.environ.get("OMP_NUM_THREADS", cores)))
+    torch.set_num_threads(cores)
+    sd = seeded_state_dict(spec, 0)
+    kw = dict(img_resolution=spec.img_resolution, model_channels=spec.model_channels,
+              channel_mult=spec.channel_mult, num_blocks=spec.num_blocks, label_dim=spec.label_dim)
+    calls = [0]
+
+    def model(x, t, labels):
+        calls[0] += 1
+        return unet_forward(sd, x, t, labels, **kw)
+
+    s_cpu = max(2, (n_evals + 1) // 2)
+    tr = RefTranslation(RefScheduler("ddpm"), spec.label_dim, sample_steps=1000, eta=cfg.EVAL.ETA)
+    image = synthetic_faces(1, spec.img_resolution, seed=0)
+    with torch.no_grad():
+        model(image, torch.tensor([10.0]), tr.process_label(0, 1))      # warm the CPU kernels
+        calls[0] = 0
+        t0 = time.perf_counter()
+        eps = tr.encode(image, tr.process_label(0, 1), model, start_from_step=s_cpu)
+        tr.generate(model, eps_list=eps, class_label=tr.process_label(1, 1), source_image=image,
+                    start_from_step=s_cpu)
+        dt = time.perf_counter() - t0
+    per_eval = dt / calls[0]
+    evals_per_image = 2 * num_of_step - 1
+    return {"value": 1.0 / (per_eval * evals_per_image), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"B=1 removal loop shortened to start_from_step={s_cpu} ({calls[0]} denoiser evaluations, "
+                      f"{dt:.1f} s), scaled to the {evals_per_image} evaluations per image of start_from_step="
+                      f"{num_of_step}",
+            "evals_per_s": 1.0 / per_eval}
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 with torch.distributed.run (one process per GPU)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    from mad_amd import ops
+    from mad_amd.config import load_cfg
+    from mad_amd.model import build_model
+    from mad_amd.synthetic import synthetic_faces, synthetic_parsing_map
+    from mad_amd.translation import TranslationDiffusion
+
+    cfg = load_cfg(args.config)
+    model = build_model(cfg, precision=args.precision)
+    model.unet.init_seeded(0)
+    model = model.to(dev).eval()
+    spec = model.spec
+    R, B, S = spec.img_resolution, args.batch, args.num_of_step
+    td = TranslationDiffusion(cfg, dev)
+    td.generator = torch.Generator(device=dev).manual_seed(1234 + rank)
+    # this rank's shard of the job: its own B images and parsing maps, resident in HBM
+    images = synthetic_faces(B, R, seed=100 + rank).to(dev)
+    maps = torch.stack([synthetic_parsing_map(R, seed=rank * B + i) for i in range(B)]).to(dev)
+
+    eval_count = [0]
+    inner = model.unet.forward
+
+    def counted(*a, **k):
+        # sample every n-th denoiser evaluation for per-kernel stream-event timing
+        ops.TIMER.active = timed[0] and (eval_count[0] % args.profile_every == 0)
+        eval_count[0] += 1
+        out = inner(*a, **k)
+        ops.TIMER.active = False
+        return out
+
+    timed = [False]
+    model.unet.forward = counted
+
+    def one_step():
+        return td.domain_translation(model, model, images, source_class_label=0, target_class_label=1,
+                                     parsing_mask=maps, start_from_step=S)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_step()
+    barrier()
+    timed[0] = True
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = one_step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    timed[0] = False
+    assert tuple(out.shape) == (B, 3, R, R) and bool(torch.isfinite(out).all())
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kern = ops.TIMER.summary()
+
+    if rank == 0:
+        flops_img_eval = spec.flops_per_image()["total"]
+        evals = 2 * S - 1
+        images_total = world * B * args.steps
+        value = images_total / elapsed
+        conv = kern.get("conv_igemm", {"launches": 0, "flops": 0.0, "ms": 0.0})
+        achieved = conv["flops"] / (conv["ms"] * 1e-3) / 1e12 if conv["ms"] > 0 else 0.0
+        attn = kern.get("attention", {"launches": 0, "flops": 0.0, "ms": 0.0})
+        line = {
+            "metric": "translated images/sec @256x256, fixed-step inversion+denoise (makeup removal)"
+                      if R == 256 else f"translated images/sec @{R}x{R}, fixed-step inversion+denoise",
+            "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+            "config": {"workload": f"{os.path.basename(args.config)} makeup removal (noise encoding + regeneration), "
+                                   f"DDPM 1000-step table, start_from_step={S} ({evals} denoiser evaluations per "
+                                   f"image), batch {B} per GPU, random-init (seeded) weights",
+                       "batch_per_gpu": B, "num_of_step": S, "resolution": R, "parallelism": f"dp{world}",
+                       "denoiser_evals_per_s": world * B * args.steps * evals / elapsed / B,
+                       "gflop_per_image_per_eval": flops_img_eval / 1e9},
+            "mfma_util_end_to_end": value * flops_img_eval * evals / 1e12 / (PEAK_BF16_TFLOPS * world),
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_BF16_TFLOPS, "traffic": None,
+                         "kernel": "conv_igemm_kernel (all 3x3/1x1 conv launches of the sampled evaluations)",
+                         "launches_timed": conv["launches"],
+                         "avg_launch_ms": conv["ms"] / conv["launches"] if conv["launches"] else None,
+                         "attention_tflops": attn["flops"] / (attn["ms"] * 1e-3) / 1e12 if attn["ms"] > 0 else None},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(cfg, spec, S, args.cpu_evals)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -92,7 +92,7 @@ class DhariwalUNet(nn.Module):
         self.out_conv = _Params({"weight": (s.out_channels, s.final_channels, 3, 3), "bias": (s.out_channels,)})
         self._packed = None
         self._packed_key = None
-        self._register_load_state_dict_post_hook(lambda module, incompatible: module.invalidate())
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module.invalidate())
 
     # ------------------------------------------------------------------ weights
     def invalidate(self) -> None:

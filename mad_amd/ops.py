@@ -47,6 +47,42 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+class KernelTimer:
+    """Optional per-launch timing of the MFMA kernels with events recorded on the launch stream.
+
+    While ``active`` is set, every ``conv2d`` / ``attention`` launch is bracketed by two events on
+    torch's current stream (the stream the kernel is enqueued on) and logged with its algorithmic
+    FLOPs.  ``summary()`` synchronises and returns totals per kernel.  Off by default: the timed
+    loops enable it for a sampled subset of denoiser evaluations.
+    """
+
+    def __init__(self):
+        self.active = False
+        self.records = []
+
+    def bracket(self, name: str, flops: float):
+        if not self.active:
+            return None
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        self.records.append((name, flops, a, b))
+        return b
+
+    def summary(self) -> dict:
+        torch.cuda.synchronize()
+        out: dict = {}
+        for name, flops, a, b in self.records:
+            d = out.setdefault(name, {"launches": 0, "flops": 0.0, "ms": 0.0})
+            d["launches"] += 1
+            d["flops"] += flops
+            d["ms"] += a.elapsed_time(b)
+        self.records = []
+        return out
+
+
+TIMER = KernelTimer()
+
+
 # ------------------------------------------------------------------------------ sampler
 def sampler_update(coef: SamplerCoef, model_output: Tensor, sample: Tensor,
                    noise: Optional[Tensor] = None, original: Optional[Tensor] = None,
@@ -197,8 +233,11 @@ def conv2d(x1: Tensor, w: Tensor, bias: Optional[Tensor], x2: Optional[Tensor] =
     elif res_mode != _lib.RES_NONE:
         raise ValueError("res_mode set without a residual tensor")
     y = torch.empty((B, H, W_, Cout), dtype=x1.dtype, device=x1.device)
+    end = TIMER.bracket("conv_igemm", 2.0 * B * H * W_ * Cout * (C1 + C2) * k * k)
     check(lib.mad_conv2d(_ptr(x1), C1, _ptr(x2), C2, _ptr(w), _ptr(bias), _ptr(residual), res_mode, _ptr(y),
                          _dtype_code(x1), B, H, W_, Cout, k, int(upsample), _stream()), "mad_conv2d")
+    if end is not None:
+        end.record()
     return y
 
 
@@ -249,5 +288,8 @@ def attention(qkv: Tensor, heads: int) -> Tensor:
     if C != heads * 64:
         raise ValueError(f"attention needs head_dim 64: C={C}, heads={heads}")
     out = torch.empty((B, H, W_, C), dtype=qkv.dtype, device=qkv.device)
+    end = TIMER.bracket("attention", 4.0 * B * (H * W_) ** 2 * C)
     check(lib.mad_attention(_ptr(qkv), _ptr(out), _dtype_code(qkv), B, H * W_, heads, _stream()), "mad_attention")
+    if end is not None:
+        end.record()
     return out

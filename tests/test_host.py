@@ -107,3 +107,18 @@ def test_shard_split_follows_reference():
     assert shard_bounds(3, 8, 7) == (0, 3) and shard_bounds(3, 8, 0) == (0, 0)
     with pytest.raises(ValueError):
         shard_bounds(3, 2, 2)
+
+
+def test_model_construction_and_state_dict_on_cpu():
+    """Building the model, seeding it and round-tripping a state_dict needs no GPU."""
+    from mad_amd.init import seeded_state_dict
+    from mad_amd.model import build_model
+    m = build_model(load_cfg(os.path.join(REPO, "configs", "model_tiny.yaml")))
+    m.unet.init_seeded(2)
+    sd = m.state_dict()
+    want = seeded_state_dict(m.spec, 2)
+    assert sorted(sd) == sorted(want)
+    assert all(torch.equal(sd[k], want[k]) for k in want)
+    m.load_state_dict(want)
+    with pytest.raises(RuntimeError, match="HIP kernels only"):
+        m(torch.zeros(1, 3, 16, 16), torch.tensor([1.0]))
