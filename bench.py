@@ -35,7 +35,7 @@ def parse_args():
                    help="start_from_step of the removal loop (reference default 700)")
     p.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--cpu-evals", type=int, default=6, help="denoiser evaluations in the CPU sample")
+    p.add_argument("--cpu-evals", type=int, default=40, help="denoiser evaluations in the CPU sample")
     p.add_argument("--profile-every", type=int, default=100,
                    help="bracket the MFMA kernels of every n-th denoiser evaluation with stream events")
     return p.parse_args()
