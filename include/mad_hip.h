@@ -113,6 +113,14 @@ int mad_conv_in(const float* x, const float* w, const float* bias, void* y, int 
 int mad_conv_out(const void* x, int dtype, const float* w, const float* bias, float* y, int B,
                  int Cin, int H, int W, int Cout, void* stream);
 
+/* Last convolution on the halo-tile MFMA kernel, with out_norm + SiLU folded into the loader:
+ * y (B,Cout<=32,H,W) NCHW fp32 = conv3x3(act(x*coef[...,0] + coef[...,1])) + bias.  x NHWC (B,H,W,Cin),
+ * w (32,3,3,Cin) in `dtype` with rows >= Cout zero, H and W multiples of 16.
+ * Replaces out_conv(silu(out_norm(x))) (model.py:589). */
+int mad_conv_out_fused(const void* x, int Cin, const float* coef, int act, const void* w,
+                       const float* bias, float* y, int dtype, int B, int H, int W, int Cout,
+                       void* stream);
+
 #define MAD_RES_NONE 0
 #define MAD_RES_SAME 1 /* residual (B,H,W,Cout)                                   */
 #define MAD_RES_UP 2   /* residual (B,H/2,W/2,Cout), nearest-neighbour x2         */
@@ -130,6 +138,22 @@ int mad_conv2d(const void* x1, int C1, const void* x2, int C2, const void* w, co
                const void* residual, int res_mode, void* y, int dtype, int B, int H, int W,
                int Cout, int ksize, int upsample, void* stream);
 
+/* 3x3 convolution (pad 1, stride 1) for layers with H, W multiples of 16 and Cout a multiple of 128,
+ * with the producer's GroupNorm folded into the operand loader and the consumer's GroupNorm
+ * statistics produced by the epilogue:
+ *   in(b,y,x,c) = act(x(b,y,x,c)*coef[b,c,0] + coef[b,c,1])   (coef NULL: in = x; zero outside the image)
+ *   y = conv3x3(in) + bias (+ residual as in mad_conv2d)
+ *   stats[b, tile, n, 0/1] = sum / sum of squares of y over the 16x16 tile (tile = ty*(W/16)+tx);
+ *   stats may be NULL.  mad_gn_finalize consumes it with nsplit = (H/16)*(W/16).
+ * x is the concatenation of x1 (C1) and x2 (C2), NHWC at (H,W), or at (H/2,W/2) when `upsample`.
+ * C1, C2 multiples of 32 (bf16) / 16 (fp32).  act: 0 none, 1 SiLU.
+ * Replaces GroupNorm -> SiLU -> Conv2d (model.py:341, 346-350) and the statistics pass of the
+ * GroupNorm that follows (model.py:182-190). */
+int mad_conv3x3_fused(const void* x1, int C1, const void* x2, int C2, const float* coef, int act,
+                      const void* w, const float* bias, const void* residual, int res_mode, void* y,
+                      float* stats, int dtype, int B, int H, int W, int Cout, int upsample,
+                      void* stream);
+
 /* GroupNorm statistics, pass 1: per-(sample, split, channel) sum and sum of squares over the
  * split's pixels of the concatenation of x1 (C1) and x2 (C2).  partial is fp32
  * (B, nsplit, C1+C2, 2).  HW must be a multiple of nsplit. */
@@ -139,12 +163,15 @@ int mad_gn_partial(const void* x1, int C1, const void* x2, int C2, int dtype, fl
 /* GroupNorm statistics, pass 2: reduce the partials per group and fold mean, rstd, the affine
  * gain/offset and the optional AdaGN modulation into one (a, d) pair per (sample, channel):
  *   y = x*a + d  ==  shift + ((x-mean)*rstd*gamma + beta) * (scale + 1)
+ * The channel axis is the concatenation of two slabs: partial1 fp32 (B, nsplit1, C1, 2) and
+ * partial2 fp32 (B, nsplit2, C2, 2) (NULL/0 for a single source), as written by mad_gn_partial or by
+ * the epilogue of mad_conv3x3_fused.  HW is the pixel count the sums run over.
  * ada is fp32 with row stride ada_stride: ada[b*ada_stride + c] = scale, ada[... + C + c] = shift
- * (scale first: model.py:343-346); NULL for a plain GroupNorm.  coef is fp32 (B, C, 2).
+ * (scale first: model.py:343-346); NULL for a plain GroupNorm.  coef is fp32 (B, C1+C2, 2).
  * Replaces GroupNorm.forward (model.py:182-190) statistics. */
-int mad_gn_finalize(const float* partial, const float* gamma, const float* beta, const float* ada,
-                    int ada_stride, float* coef, int B, int C, int groups, int HW, int nsplit,
-                    float eps, void* stream);
+int mad_gn_finalize(const float* partial1, int C1, int nsplit1, const float* partial2, int C2,
+                    int nsplit2, const float* gamma, const float* beta, const float* ada,
+                    int ada_stride, float* coef, int B, int groups, int HW, float eps, void* stream);
 
 /* y = act(x*a + d) over the concatenation of x1/x2, written as one (B,H,W,C1+C2) tensor
  * (or (B,H/2,W/2,C) with the 2x2 mean of the activated values when `pool` is set: the `down`

@@ -41,10 +41,15 @@ SIGNATURES = {
     "mad_pos_embedding": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "mad_conv_in": (c_int, [c_void_p] * 4 + [c_int] * 6 + [c_void_p]),
     "mad_conv_out": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p] + [c_int] * 5 + [c_void_p]),
+    "mad_conv_out_fused": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p] + [c_int] * 5
+                           + [c_void_p]),
     "mad_conv2d": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p]
                    + [c_int] * 7 + [c_void_p]),
+    "mad_conv3x3_fused": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+                                  c_int, c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
     "mad_gn_partial": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
-    "mad_gn_finalize": (c_int, [c_void_p] * 4 + [c_int, c_void_p] + [c_int] * 5 + [c_float, c_void_p]),
+    "mad_gn_finalize": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int,
+                                c_void_p, c_int, c_int, c_int, c_float, c_void_p]),
     "mad_gn_apply": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
     "mad_attention": (c_int, [c_void_p, c_void_p] + [c_int] * 4 + [c_void_p]),
 }

@@ -216,45 +216,71 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
 }
 
 // --------------------------------------------------------------------------- first layer
-// 64 consecutive pixels per block; thread (p = tid&63, cg = tid>>6) computes channel chunks
-// cg, cg+4, ... of pixel p from its 27 input taps held in registers.
+// 64 consecutive pixels per block.  Thread (p = tid&63, cg = tid>>6) computes 32-channel groups
+// cg, cg+4, ... of pixel p from its 27 input taps held in registers; weights sit in LDS transposed
+// ([k][Cout]) so four output channels come from one broadcast ds_read_b128.  The output tile is
+// staged in LDS and written out as whole contiguous rows.
 template <typename T, int Cin>
 __global__ __launch_bounds__(256) void conv_in_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                        const float* __restrict__ bias, T* __restrict__ y, int B,
                                                        int H, int W, int Cout) {
     constexpr int VEC = Elem<T>::VEC;
-    extern __shared__ __attribute__((aligned(16))) float wl[];   // [Cout][Cin*9] then bias[Cout]
     constexpr int K = Cin * 9;
-    for (int i = threadIdx.x; i < Cout * K; i += 256) wl[i] = w[i];
-    for (int i = threadIdx.x; i < Cout; i += 256) wl[Cout * K + i] = bias[i];
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_in[];
+    float* wT = reinterpret_cast<float*>(smem_in);                    // [K][Cout]
+    float* bl = wT + K * Cout;                                        // [Cout]
+    T* otile = reinterpret_cast<T*>(bl + Cout);                       // [64][Cout]
+    for (int i = threadIdx.x; i < Cout * K; i += 256) { const int n = i / K, k = i - n * K; wT[k * Cout + n] = w[i]; }
+    for (int i = threadIdx.x; i < Cout; i += 256) bl[i] = bias[i];
     __syncthreads();
     const int HW = H * W;
-    const size_t m = (size_t)blockIdx.x * 64 + (threadIdx.x & 63);
-    if (m >= (size_t)B * HW) return;
-    const int b = (int)(m / HW), rem = (int)(m % HW), oy = rem / W, ox = rem % W;
+    const size_t total = (size_t)B * HW;
+    const size_t m0 = (size_t)blockIdx.x * 64;
+    const int p = threadIdx.x & 63;
+    const size_t m = m0 + p;
     float in[K];
+    if (m < total) {
+        const int b = (int)(m / HW), rem = (int)(m % HW), oy = rem / W, ox = rem % W;
 #pragma unroll
-    for (int c = 0; c < Cin; ++c)
+        for (int c = 0; c < Cin; ++c)
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
+            for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                const int iy = oy + ky - 1, ix = ox + kx - 1;
-                const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
-                in[c * 9 + ky * 3 + kx] = ok ? x[((size_t)(b * Cin + c) * H + iy) * W + ix] : 0.0f;
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int iy = oy + ky - 1, ix = ox + kx - 1;
+                    const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
+                    in[c * 9 + ky * 3 + kx] = ok ? x[((size_t)(b * Cin + c) * H + iy) * W + ix] : 0.0f;
+                }
+    } else {
+#pragma unroll
+        for (int k = 0; k < K; ++k) in[k] = 0.0f;
+    }
+    for (int n0 = (threadIdx.x >> 6) * 32; n0 < Cout; n0 += 128) {
+#pragma unroll
+        for (int g = 0; g < 32; g += VEC) {
+            float v[VEC];
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) v[i] = bl[n0 + g + i];
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+#pragma unroll
+                for (int i = 0; i < VEC; i += 4) {
+                    const float4 ww = *reinterpret_cast<const float4*>(wT + k * Cout + n0 + g + i);
+                    v[i] = fmaf(in[k], ww.x, v[i]); v[i + 1] = fmaf(in[k], ww.y, v[i + 1]);
+                    v[i + 2] = fmaf(in[k], ww.z, v[i + 2]); v[i + 3] = fmaf(in[k], ww.w, v[i + 3]);
+                }
             }
-    for (int chunk = threadIdx.x >> 6; chunk < Cout / VEC; chunk += 4) {
-        float v[VEC];
-#pragma unroll
-        for (int i = 0; i < VEC; ++i) {
-            const int n = chunk * VEC + i;
-            float s = wl[Cout * K + n];
-#pragma unroll
-            for (int k = 0; k < K; ++k) s = fmaf(in[k], wl[n * K + k], s);
-            v[i] = s;
+            Vec16<T> o; o.pack(v);
+            o.store(otile + p * Cout + n0 + g);
         }
-        Vec16<T> o; o.pack(v);
-        o.store(y + m * Cout + chunk * VEC);
+    }
+    __syncthreads();
+    // 64 pixels x Cout channels are contiguous in NHWC: copy the tile out in 16-byte pieces
+    const int chunks = 64 * Cout / VEC;
+    T* dst = y + m0 * Cout;
+    for (int i = threadIdx.x; i < chunks; i += 256) {
+        if (m0 + (size_t)(i * VEC) / Cout < total)
+            *reinterpret_cast<uint4*>(dst + (size_t)i * VEC) = *reinterpret_cast<const uint4*>(otile + (size_t)i * VEC);
     }
 }
 
@@ -342,10 +368,10 @@ extern "C" int mad_conv_in(const float* x, const float* w, const float* bias, vo
     MAD_REQUIRE(x && w && bias && y, "mad_conv_in: null pointer");
     MAD_REQUIRE(dtype == MAD_BF16 || dtype == MAD_F32, "mad_conv_in: bad dtype %d", dtype);
     MAD_REQUIRE(Cin == 3, "mad_conv_in: Cin=%d, only 3 input channels are built", Cin);
-    MAD_REQUIRE(Cout > 0 && Cout % 8 == 0 && Cout <= 512, "mad_conv_in: Cout=%d must be a multiple of 8, <= 512", Cout);
+    MAD_REQUIRE(Cout > 0 && Cout % 32 == 0 && Cout <= 256, "mad_conv_in: Cout=%d must be a multiple of 32, <= 256", Cout);
     MAD_REQUIRE(B > 0 && H > 0 && W > 0, "mad_conv_in: bad shape");
     const size_t M = (size_t)B * H * W;
-    const size_t lds = ((size_t)Cout * Cin * 9 + Cout) * sizeof(float);
+    const size_t lds = ((size_t)Cout * Cin * 9 + Cout) * sizeof(float) + (size_t)64 * Cout * (dtype == MAD_BF16 ? 2 : 4);
     dim3 grid((unsigned)((M + 63) / 64));
     if (dtype == MAD_BF16)
         hipLaunchKernelGGL((conv_in_kernel<bf16_t, 3>), grid, dim3(256), lds, (hipStream_t)stream, x, w, bias,

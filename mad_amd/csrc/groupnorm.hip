@@ -70,45 +70,38 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const T* __restrict__ x
 }
 
 // ------------------------------------------------------------------------------- finalize
-// grid (B), 256 threads.  One thread per group computes mean/rstd in fp64 from the partials, then
-// all threads write the per-channel (a, d) pairs.
-__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ partial,
-                                                           const float* __restrict__ gamma,
-                                                           const float* __restrict__ beta,
-                                                           const float* __restrict__ ada, int ada_stride,
-                                                           float* __restrict__ coef, int C, int groups, int HW,
-                                                           int nsplit, float eps) {
-    __shared__ float mean_s[64], rstd_s[64];
-    const int b = blockIdx.x;
-    const int cpg = C / groups;
-    // 4 threads per group share the (split, channel) pairs, combined in a fixed order
-    const int g = threadIdx.x >> 2, sub = threadIdx.x & 3;
-    if (g < groups) {
-        double s = 0.0, q = 0.0;
-        const int items = nsplit * cpg;
-        for (int it = sub; it < items; it += 4) {
-            const int sp = it / cpg, c = g * cpg + it % cpg;
-            const float* p = partial + (((size_t)b * nsplit + sp) * C + c) * 2;
-            s += (double)p[0];
-            q += (double)p[1];
-        }
-        s += __shfl_xor(s, 1); q += __shfl_xor(q, 1);
-        s += __shfl_xor(s, 2); q += __shfl_xor(q, 2);
-        if (sub == 0) {
-            const double n = (double)HW * cpg;
-            const double mean = s / n;
-            double var = q / n - mean * mean;
-            if (var < 0.0) var = 0.0;
-            mean_s[g] = (float)mean;
-            rstd_s[g] = (float)(1.0 / sqrt(var + (double)eps));
-        }
+// grid (groups, B), one wave per (sample, group).  The channel axis is the concatenation of two
+// partial-sum slabs (C1 channels in nsplit1 splits, C2 channels in nsplit2 splits).  Partials are
+// combined in fp64 in a fixed order, then the lanes write the per-channel (a, d) pairs.
+__global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict__ partial1, int C1, int nsplit1,
+                                                          const float* __restrict__ partial2, int C2, int nsplit2,
+                                                          const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta,
+                                                          const float* __restrict__ ada, int ada_stride,
+                                                          float* __restrict__ coef, int groups, int HW, float eps) {
+    const int g = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+    const int C = C1 + C2, cpg = C / groups;
+    const int max_ns = nsplit1 > nsplit2 ? nsplit1 : nsplit2;
+    double s = 0.0, q = 0.0;
+    for (int it = lane; it < cpg * max_ns; it += 64) {
+        const int c = g * cpg + it / max_ns, sp = it % max_ns;
+        const float* p = nullptr;
+        if (c < C1) { if (sp < nsplit1) p = partial1 + (((size_t)b * nsplit1 + sp) * C1 + c) * 2; }
+        else { if (sp < nsplit2) p = partial2 + (((size_t)b * nsplit2 + sp) * C2 + (c - C1)) * 2; }
+        if (p) { s += (double)p[0]; q += (double)p[1]; }
     }
-    __syncthreads();
-    for (int c = threadIdx.x; c < C; c += 256) {
-        const int gg = c / cpg;
-        const float rg = rstd_s[gg] * gamma[c];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { s += __shfl_xor(s, off); q += __shfl_xor(q, off); }
+    const double n = (double)HW * cpg;
+    const double mean = s / n;
+    double var = q / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float mean_f = (float)mean, rstd_f = (float)(1.0 / sqrt(var + (double)eps));
+    for (int i = lane; i < cpg; i += 64) {
+        const int c = g * cpg + i;
+        const float rg = rstd_f * gamma[c];
         float a = rg;
-        float d = beta[c] - mean_s[gg] * rg;
+        float d = beta[c] - mean_f * rg;
         if (ada) {
             const float sc = ada[(size_t)b * ada_stride + c] + 1.0f;
             const float sh = ada[(size_t)b * ada_stride + C + c];
@@ -212,15 +205,17 @@ extern "C" int mad_gn_partial(const void* x1, int C1, const void* x2, int C2, in
     return check_launch("mad_gn_partial");
 }
 
-extern "C" int mad_gn_finalize(const float* partial, const float* gamma, const float* beta, const float* ada,
-                               int ada_stride, float* coef, int B, int C, int groups, int HW, int nsplit, float eps,
-                               void* stream) {
-    MAD_REQUIRE(partial && gamma && beta && coef, "mad_gn_finalize: null pointer");
-    MAD_REQUIRE(B > 0 && C > 0 && groups > 0 && groups <= 64 && C % groups == 0,
-                "mad_gn_finalize: bad C=%d groups=%d", C, groups);
-    MAD_REQUIRE(HW > 0 && nsplit > 0, "mad_gn_finalize: bad HW/nsplit");
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, partial, gamma, beta, ada,
-                       ada_stride, coef, C, groups, HW, nsplit, eps);
+extern "C" int mad_gn_finalize(const float* partial1, int C1, int nsplit1, const float* partial2, int C2, int nsplit2,
+                               const float* gamma, const float* beta, const float* ada, int ada_stride, float* coef,
+                               int B, int groups, int HW, float eps, void* stream) {
+    MAD_REQUIRE(partial1 && gamma && beta && coef, "mad_gn_finalize: null pointer");
+    MAD_REQUIRE(C1 > 0 && nsplit1 > 0 && C2 >= 0 && (C2 == 0 || (partial2 && nsplit2 > 0)),
+                "mad_gn_finalize: bad partial-sum layout C1=%d nsplit1=%d C2=%d nsplit2=%d", C1, nsplit1, C2, nsplit2);
+    MAD_REQUIRE(B > 0 && groups > 0 && (C1 + C2) % groups == 0, "mad_gn_finalize: bad C=%d groups=%d", C1 + C2, groups);
+    MAD_REQUIRE(HW > 0, "mad_gn_finalize: bad HW");
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, B), dim3(64), 0, (hipStream_t)stream, partial1, C1, nsplit1,
+                       C2 ? partial2 : partial1, C2, C2 ? nsplit2 : 1, gamma, beta, ada, ada_stride, coef, groups, HW,
+                       eps);
     return check_launch("mad_gn_finalize");
 }
 

@@ -164,36 +164,66 @@ class DhariwalUNet(nn.Module):
         P["out_norm.g"], P["out_norm.b"] = f32("out_norm.weight"), f32("out_norm.bias")
         P["out.w"] = sd["out_conv.weight"].to(torch.float32).permute(0, 2, 3, 1).contiguous()   # fp32 (Cout,3,3,Cin)
         P["out.b"] = f32("out_conv.bias")
+        w32 = torch.zeros((32, 3, 3, s.final_channels), dtype=torch.float32, device=device)
+        w32[:s.out_channels] = P["out.w"]
+        P["out.w32"] = w32.to(dt)                  # zero-padded to one 32-wide MFMA column tile
         self._packed, self._packed_key = P, key
         return P
 
     # ------------------------------------------------------------------ forward
-    def _block(self, e: dict, x: Tensor, skip: Optional[Tensor], ada: Tensor, ada_total: int) -> Tensor:
+    @staticmethod
+    def _part(a: "_Act") -> Tensor:
+        """GroupNorm partial sums of an activation: taken from the producing conv's epilogue when it
+        wrote them, otherwise computed once by the statistics kernel and cached."""
+        if a.part is None:
+            a.part = ops.gn_partial(a.t)
+        return a.part
+
+    def _block(self, e: dict, x: "_Act", skip: Optional["_Act"], ada: Tensor, ada_total: int) -> "_Act":
         b: BlockSpec = e["spec"]
-        # norm0 + SiLU over the (virtual) concatenation, optionally 2x2-averaged for `down`
-        c0 = ops.gn_coef(x, e["norm0.g"], e["norm0.b"], gn_groups(b.in_channels), GN_EPS, x2=skip)
-        h = ops.gn_apply(x, c0, act=True, x2=skip, pool=b.down)
-        h = ops.conv2d(h, e["conv0.w"], e["conv0.b"], upsample=b.up)
-        # norm1 with AdaGN modulation + SiLU
-        c1 = ops.gn_coef(h, e["norm1.g"], e["norm1.b"], gn_groups(b.out_channels), GN_EPS,
-                         ada=ada[:, e["ada_off"]:], ada_stride=ada_total)
-        h = ops.gn_apply(h, c1, act=True)
+        hw_in, hw_out = b.res_in * b.res_in, b.res_out * b.res_out
+        xt, st = x.t, (None if skip is None else skip.t)
+        # norm0 over the (virtual) concatenation [x, skip]
+        c0 = ops.gn_finalize(self._part(x), hw_in, e["norm0.g"], e["norm0.b"], gn_groups(b.in_channels), GN_EPS,
+                             partial2=None if skip is None else self._part(skip))
+        ada_v = ada[:, e["ada_off"]:]
         if b.skip_conv:
-            res, mode = ops.conv2d(x, e["skip.w"], e["skip.b"], x2=skip), _lib.RES_SAME
+            res, mode = ops.conv2d(xt, e["skip.w"], e["skip.b"], x2=st), _lib.RES_SAME
         elif b.up:
-            res, mode = x, _lib.RES_UP
+            res, mode = xt, _lib.RES_UP
         elif b.down:
-            res, mode = x, _lib.RES_DOWN
+            res, mode = xt, _lib.RES_DOWN
         else:
-            res, mode = x, _lib.RES_SAME
-        x = ops.conv2d(h, e["conv1.w"], e["conv1.b"], residual=res, res_mode=mode)
+            res, mode = xt, _lib.RES_SAME
+        if ops.fused_conv_ok(b.res_out, b.res_out, b.out_channels):
+            # halo-tile convs: norm+SiLU of the input applied in the loader, statistics of the output
+            # taken in the epilogue
+            if b.down:
+                h = ops.gn_apply(xt, c0, act=True, x2=st, pool=True)       # 2x2 mean after norm+SiLU
+                h, part = ops.conv3x3_fused(h, e["conv0.w"], e["conv0.b"], coef=None, want_stats=True)
+            else:
+                h, part = ops.conv3x3_fused(xt, e["conv0.w"], e["conv0.b"], coef=c0, act=True, x2=st,
+                                            upsample=b.up, want_stats=True)
+            c1 = ops.gn_finalize(part, hw_out, e["norm1.g"], e["norm1.b"], gn_groups(b.out_channels), GN_EPS,
+                                 ada=ada_v, ada_stride=ada_total)
+            y, part = ops.conv3x3_fused(h, e["conv1.w"], e["conv1.b"], coef=c1, act=True, residual=res,
+                                        res_mode=mode, want_stats=True)
+            out = _Act(y, part)
+        else:
+            h = ops.gn_apply(xt, c0, act=True, x2=st, pool=b.down)
+            h = ops.conv2d(h, e["conv0.w"], e["conv0.b"], upsample=b.up)
+            c1 = ops.gn_coef(h, e["norm1.g"], e["norm1.b"], gn_groups(b.out_channels), GN_EPS,
+                             ada=ada_v, ada_stride=ada_total)
+            h = ops.gn_apply(h, c1, act=True)
+            out = _Act(ops.conv2d(h, e["conv1.w"], e["conv1.b"], residual=res, res_mode=mode))
         if b.attention:
-            c2 = ops.gn_coef(x, e["norm2.g"], e["norm2.b"], gn_groups(b.out_channels), GN_EPS)
-            h = ops.gn_apply(x, c2, act=False)
+            c2 = ops.gn_finalize(self._part(out), hw_out, e["norm2.g"], e["norm2.b"], gn_groups(b.out_channels),
+                                 GN_EPS)
+            h = ops.gn_apply(out.t, c2, act=False)
             qkv = ops.conv2d(h, e["qkv.w"], e["qkv.b"])
             a = ops.attention(qkv, b.num_heads)
-            x = ops.conv2d(a, e["proj.w"], e["proj.b"], residual=x, res_mode=_lib.RES_SAME)
-        return x
+            out = _Act(ops.conv2d(a, e["proj.w"], e["proj.b"], residual=out.t, res_mode=_lib.RES_SAME))
+        return out
 
     @torch.no_grad()
     def forward(self, x: Tensor, noise_labels: Tensor, class_labels: Optional[Tensor] = None,
@@ -232,10 +262,10 @@ class DhariwalUNet(nn.Module):
         if taps is not None:
             taps["emb"] = emb
 
-        h = ops.conv_in(x, P["in.w"], P["in.b"], dt)
+        h = _Act(ops.conv_in(x, P["in.w"], P["in.b"], dt))
         skips = [h]
         if taps is not None:
-            taps[s.enc_conv_name] = h
+            taps[s.enc_conv_name] = h.t
         n_enc = len(s.enc)
         for i, e in enumerate(P["blocks"]):
             b: BlockSpec = e["spec"]
@@ -245,10 +275,22 @@ class DhariwalUNet(nn.Module):
             else:
                 h = self._block(e, h, skips.pop() if b.cat_skip else None, ada, total)
             if taps is not None:
-                taps[b.name] = h
-        c = ops.gn_coef(h, P["out_norm.g"], P["out_norm.b"], gn_groups(s.final_channels), GN_EPS)
-        h = ops.gn_apply(h, c, act=True)
-        return (ops.conv_out(h, P["out.w"], P["out.b"]),)
+                taps[b.name] = h.t
+        c = ops.gn_finalize(self._part(h), s.img_resolution ** 2, P["out_norm.g"], P["out_norm.b"],
+                            gn_groups(s.final_channels), GN_EPS)
+        R = s.img_resolution
+        if R % 16 == 0 and s.out_channels <= 32 and s.final_channels % 32 == 0:
+            return (ops.conv_out_fused(h.t, P["out.w32"], P["out.b"], s.out_channels, coef=c, act=True),)
+        y = ops.gn_apply(h.t, c, act=True)
+        return (ops.conv_out(y, P["out.w"], P["out.b"]),)
+
+
+class _Act:
+    """An NHWC activation together with its GroupNorm partial sums (B, nsplit, C, 2), if known."""
+    __slots__ = ("t", "part")
+
+    def __init__(self, t: Tensor, part: Optional[Tensor] = None):
+        self.t, self.part = t, part
 
 
 class Denoiser(nn.Module):

@@ -211,6 +211,24 @@ def conv_out(x: Tensor, w: Tensor, bias: Tensor) -> Tensor:
     return y
 
 
+def conv_out_fused(x: Tensor, w32: Tensor, bias: Tensor, cout: int, coef: Optional[Tensor] = None,
+                   act: bool = True) -> Tensor:
+    """Last layer on the MFMA halo kernel: x NHWC, w32 (32,3,3,Cin) zero-padded rows, -> NCHW fp32."""
+    _dev(x, w32, bias, coef)
+    B, H, W_, Cin = x.shape
+    if w32.dtype != x.dtype or tuple(w32.shape) != (32, 3, 3, Cin) or bias.dtype != torch.float32:
+        raise ValueError("conv_out_fused needs (32,3,3,Cin) weights in the activation dtype and fp32 bias")
+    if coef is not None and (coef.dtype != torch.float32 or tuple(coef.shape) != (B, Cin, 2)):
+        raise ValueError("conv_out_fused coef must be fp32 (B, Cin, 2)")
+    y = torch.empty((B, cout, H, W_), dtype=torch.float32, device=x.device)
+    end = TIMER.bracket("conv_out", 2.0 * B * H * W_ * cout * Cin * 9)
+    check(lib.mad_conv_out_fused(_ptr(x), Cin, _ptr(coef), int(act), _ptr(w32), _ptr(bias), _ptr(y), _dtype_code(x),
+                                 B, H, W_, cout, _stream()), "mad_conv_out_fused")
+    if end is not None:
+        end.record()
+    return y
+
+
 def conv2d(x1: Tensor, w: Tensor, bias: Optional[Tensor], x2: Optional[Tensor] = None,
            residual: Optional[Tensor] = None, res_mode: int = _lib.RES_NONE, upsample: bool = False) -> Tensor:
     """Implicit-GEMM conv; x NHWC, w (Cout,k,k,C1+C2) in the activation dtype, bias fp32."""
@@ -241,31 +259,84 @@ def conv2d(x1: Tensor, w: Tensor, bias: Optional[Tensor], x2: Optional[Tensor] =
     return y
 
 
+def conv3x3_fused(x1: Tensor, w: Tensor, bias: Optional[Tensor], coef: Optional[Tensor] = None, act: bool = True,
+                  x2: Optional[Tensor] = None, residual: Optional[Tensor] = None, res_mode: int = _lib.RES_NONE,
+                  upsample: bool = False, want_stats: bool = False):
+    """Halo-tile 3x3 conv with the input's GroupNorm(+SiLU) applied in the loader (coef (B,C,2) or None)
+    and, optionally, per-tile statistics of the output (B, tiles, Cout, 2) for the next GroupNorm."""
+    _dev(x1, x2, w, bias, coef, residual)
+    B, Hs, Ws, C1 = x1.shape
+    C2 = 0 if x2 is None else x2.shape[3]
+    H, W_ = (2 * Hs, 2 * Ws) if upsample else (Hs, Ws)
+    Cout = w.shape[0]
+    if w.dtype != x1.dtype or tuple(w.shape) != (Cout, 3, 3, C1 + C2):
+        raise ValueError(f"conv3x3_fused weight {tuple(w.shape)}/{w.dtype} does not match input {C1}+{C2}/{x1.dtype}")
+    if coef is not None and (coef.dtype != torch.float32 or tuple(coef.shape) != (B, C1 + C2, 2)):
+        raise ValueError("conv3x3_fused coef must be fp32 (B, C, 2)")
+    if residual is not None:
+        want = {_lib.RES_SAME: (B, H, W_, Cout), _lib.RES_UP: (B, H // 2, W_ // 2, Cout),
+                _lib.RES_DOWN: (B, 2 * H, 2 * W_, Cout)}.get(res_mode)
+        if want is None or tuple(residual.shape) != want or residual.dtype != x1.dtype:
+            raise ValueError(f"conv3x3_fused residual {tuple(residual.shape)} does not fit mode {res_mode}")
+    elif res_mode != _lib.RES_NONE:
+        raise ValueError("res_mode set without a residual tensor")
+    y = torch.empty((B, H, W_, Cout), dtype=x1.dtype, device=x1.device)
+    stats = torch.empty((B, (H // 16) * (W_ // 16), Cout, 2), dtype=torch.float32, device=x1.device) if want_stats else None
+    end = TIMER.bracket("conv3x3_halo", 2.0 * B * H * W_ * Cout * (C1 + C2) * 9)
+    check(lib.mad_conv3x3_fused(_ptr(x1), C1, _ptr(x2), C2, _ptr(coef), int(act), _ptr(w), _ptr(bias), _ptr(residual),
+                                res_mode, _ptr(y), _ptr(stats), _dtype_code(x1), B, H, W_, Cout, int(upsample),
+                                _stream()), "mad_conv3x3_fused")
+    if end is not None:
+        end.record()
+    return (y, stats) if want_stats else y
+
+
+def fused_conv_ok(H: int, W_: int, Cout: int) -> bool:
+    """Shapes the halo-tile kernel covers."""
+    return H % 16 == 0 and W_ % 16 == 0 and H >= 16 and W_ >= 16 and Cout % 128 == 0
+
+
 # ------------------------------------------------------------------------------ GroupNorm
 def gn_nsplit(HW: int) -> int:
     return min(64, max(1, HW // 64))
 
 
-def gn_coef(x1: Tensor, gamma: Tensor, beta: Tensor, groups: int, eps: float, x2: Optional[Tensor] = None,
-            ada: Optional[Tensor] = None, ada_stride: int = 0) -> Tensor:
-    """Statistics + folding: returns coef (B, C, 2) with y = x*a + d.  `ada` is a view whose
-    data pointer is the first scale element of sample 0; rows are `ada_stride` floats apart."""
-    _dev(x1, x2, gamma, beta)
+def gn_partial(x1: Tensor, x2: Optional[Tensor] = None) -> Tensor:
+    """Per-(sample, split, channel) sum / sum of squares: (B, nsplit, C, 2)."""
+    _dev(x1, x2)
     B, H, W_, C1 = x1.shape
     C2 = 0 if x2 is None else x2.shape[3]
-    C = C1 + C2
     HW = H * W_
     nsplit = gn_nsplit(HW)
-    partial = torch.empty((B, nsplit, C, 2), dtype=torch.float32, device=x1.device)
+    partial = torch.empty((B, nsplit, C1 + C2, 2), dtype=torch.float32, device=x1.device)
     check(lib.mad_gn_partial(_ptr(x1), C1, _ptr(x2), C2, _dtype_code(x1), _ptr(partial), B, HW, nsplit, _stream()),
           "mad_gn_partial")
-    coef = torch.empty((B, C, 2), dtype=torch.float32, device=x1.device)
+    return partial
+
+
+def gn_finalize(partial: Tensor, HW: int, gamma: Tensor, beta: Tensor, groups: int, eps: float,
+                ada: Optional[Tensor] = None, ada_stride: int = 0, partial2: Optional[Tensor] = None) -> Tensor:
+    """Partial sums (B, nsplit, C, 2) over HW pixels (optionally a second slab for concatenated
+    channels) -> coef (B, C, 2) with y = x*a + d."""
+    _dev(partial, partial2, gamma, beta)
+    B, ns1, C1, _ = partial.shape
+    ns2, C2 = (0, 0) if partial2 is None else (partial2.shape[1], partial2.shape[2])
+    C = C1 + C2
     if gamma.numel() != C or beta.numel() != C:
         raise ValueError("GroupNorm gain/offset length does not match the channel count")
-    check(lib.mad_gn_finalize(_ptr(partial), _ptr(gamma), _ptr(beta), None if ada is None else ada.data_ptr(),
-                              ada_stride, _ptr(coef), B, C, groups, HW, nsplit, float(eps), _stream()),
-          "mad_gn_finalize")
+    coef = torch.empty((B, C, 2), dtype=torch.float32, device=partial.device)
+    check(lib.mad_gn_finalize(_ptr(partial), C1, ns1, _ptr(partial2), C2, ns2, _ptr(gamma), _ptr(beta),
+                              None if ada is None else ada.data_ptr(), ada_stride, _ptr(coef), B, groups, HW,
+                              float(eps), _stream()), "mad_gn_finalize")
     return coef
+
+
+def gn_coef(x1: Tensor, gamma: Tensor, beta: Tensor, groups: int, eps: float, x2: Optional[Tensor] = None,
+            ada: Optional[Tensor] = None, ada_stride: int = 0) -> Tensor:
+    """Statistics + folding in one call: returns coef (B, C, 2) with y = x*a + d.  `ada` is a view
+    whose data pointer is the first scale element of sample 0; rows are `ada_stride` floats apart."""
+    B, H, W_, _ = x1.shape
+    return gn_finalize(gn_partial(x1, x2), H * W_, gamma, beta, groups, eps, ada=ada, ada_stride=ada_stride)
 
 
 def gn_apply(x1: Tensor, coef: Tensor, act: bool, x2: Optional[Tensor] = None, pool: bool = False) -> Tensor:

@@ -216,6 +216,16 @@ def test_conv_in_out(dev, dt):
     hq = h.to(dt).float()
     yo = ops.conv_out(_nhwc(h, dt, dev), wo.permute(0, 2, 3, 1).contiguous().to(dev), bo.to(dev))
     assert rel_err(yo.cpu(), F.conv2d(hq, wo, bo, padding=1)) < 1e-5
+    # the MFMA form of the last layer, with norm + SiLU folded into its loader
+    coef = torch.stack([1 + 0.3 * _rand((2, 64), 7), 0.3 * _rand((2, 64), 8)], dim=-1)
+    w32 = torch.zeros(32, 3, 3, 64)
+    w32[:3] = wo.permute(0, 2, 3, 1)
+    hin = F.silu(hq.double() * coef[..., 0].double()[:, :, None, None] + coef[..., 1].double()[:, :, None, None])
+    hin = hin.float().to(dt).double()
+    want = F.conv2d(hin, w32[:3].permute(0, 3, 1, 2).to(dt).double(), bo.double(), padding=1)
+    yf = ops.conv_out_fused(_nhwc(h, dt, dev), w32.to(dt).to(dev), bo.to(dev), 3, coef=coef.contiguous().to(dev))
+    assert tuple(yf.shape) == (2, 3, 16, 16)
+    assert rel_err(yf.cpu(), want) < 2e-5
 
 
 # ------------------------------------------------------------------------------ GroupNorm
@@ -275,3 +285,65 @@ def test_attention(dev, B, L, heads, dt):
     qkv = torch.cat([q, k, v], dim=-1).permute(0, 2, 1, 3).reshape(B, side, side, heads * 192)
     out = ops.attention(qkv.contiguous().to(dt).to(dev), heads)
     assert rel_err(out.float().cpu().reshape(B, L, heads * 64), want) < (2e-5 if dt == torch.float32 else 1.2e-2)
+
+
+# ------------------------------------------------------------------------------ fused halo conv
+FUSED_CASES = [
+    # B, H, C1, C2, Cout, fuse, up, res, stats
+    (2, 16, 64, 0, 128, True, False, "none", True),
+    (1, 32, 128, 0, 128, True, False, "same", True),
+    (2, 32, 64, 64, 256, True, False, "none", False),     # concat, two n tiles
+    (1, 32, 128, 0, 128, True, True, "up", True),         # nearest x2 of a 16x16 source
+    (1, 32, 64, 0, 128, False, False, "down", False),     # plain input, 2x2-mean residual
+    (1, 64, 160, 0, 128, True, False, "same", True),      # 5 bf16 chunks / 10 fp32 chunks
+]
+
+
+@pytest.mark.parametrize("case", FUSED_CASES)
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_conv3x3_fused(dev, case, dt):
+    from mad_amd import _lib, ops
+    B, H, C1, C2, Cout, fuse, up, res, want_stats = case
+    C = C1 + C2
+    Hs = H // 2 if up else H
+    x1 = _rand((B, C1, Hs, Hs), 1, 1.3) + 0.2
+    x2 = _rand((B, C2, Hs, Hs), 2) if C2 else None
+    w = _rand((Cout, C, 3, 3), 3, 1.0 / math.sqrt(C * 9))
+    bias = _rand((Cout,), 4)
+    coef = torch.stack([1 + 0.3 * _rand((B, C), 5), 0.3 * _rand((B, C), 6)], dim=-1) if fuse else None
+    rshape = {"none": None, "same": (B, Cout, H, H), "up": (B, Cout, H // 2, H // 2), "down": (B, Cout, 2 * H, 2 * H)}[res]
+    r = _rand(rshape, 7) if rshape else None
+    q = (lambda t: t.to(dt).float()) if dt == torch.bfloat16 else (lambda t: t)
+    xin = q(x1) if x2 is None else torch.cat([q(x1), q(x2)], 1)
+    xin = xin.double()
+    if fuse:
+        xin = F.silu(xin * coef[..., 0].double()[:, :, None, None] + coef[..., 1].double()[:, :, None, None])
+        xin = q(xin.float()).double()                      # the loader rounds the activated value to the storage type
+    if up:
+        xin = xin.repeat_interleave(2, 2).repeat_interleave(2, 3)
+    want = F.conv2d(xin, q(w).double(), bias.double(), padding=1)
+    if res == "same":
+        want = want + q(r).double()
+    elif res == "up":
+        want = want + q(r).double().repeat_interleave(2, 2).repeat_interleave(2, 3)
+    elif res == "down":
+        want = want + F.avg_pool2d(q(r).double(), 2)
+    mode = {"none": _lib.RES_NONE, "same": _lib.RES_SAME, "up": _lib.RES_UP, "down": _lib.RES_DOWN}[res]
+    out = ops.conv3x3_fused(_nhwc(x1, dt, dev), w.permute(0, 2, 3, 1).contiguous().to(dt).to(dev), bias.to(dev),
+                            coef=None if coef is None else coef.contiguous().to(dev), act=True,
+                            x2=None if x2 is None else _nhwc(x2, dt, dev),
+                            residual=None if r is None else _nhwc(r, dt, dev), res_mode=mode, upsample=up,
+                            want_stats=want_stats)
+    y, stats = out if want_stats else (out, None)
+    tol = 3e-5 if dt == torch.float32 else 8e-3
+    assert rel_err(_nchw(y), want) < tol
+    if want_stats:
+        yy = _nchw(y).double()                            # statistics are taken over the stored values
+        tiles = yy.reshape(B, Cout, H // 16, 16, H // 16, 16).permute(0, 2, 4, 1, 3, 5).reshape(B, -1, Cout, 256)
+        assert rel_err(stats[..., 0].cpu(), tiles.sum(-1)) < 1e-4
+        assert rel_err(stats[..., 1].cpu(), (tiles ** 2).sum(-1)) < 1e-4
+        # and they feed the finalize kernel exactly like the partial-sum kernel's output does
+        gamma, beta = 1 + 0.2 * _rand((Cout,), 8), 0.2 * _rand((Cout,), 9)
+        c1 = ops.gn_finalize(stats, H * H, gamma.to(dev), beta.to(dev), 32, 1e-5)
+        c2 = ops.gn_coef(y, gamma.to(dev), beta.to(dev), 32, 1e-5)
+        assert rel_err(c1.cpu(), c2.cpu()) < 1e-4

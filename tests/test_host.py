@@ -37,6 +37,7 @@ def test_rejections_happen_before_launch():
     assert b"multiples of 64" in lib.mad_last_error()
     assert lib.mad_attention(1, 1, 0, 1, 48, 1, None) != 0
     assert lib.mad_gn_partial(1, 64, None, 0, 0, 1, 1, 100, 3, None) != 0
+    assert lib.mad_gn_finalize(1, 64, 1, None, 0, 0, 1, 1, None, 0, 1, 1, 7, 64, 1e-5, None) != 0
     c = SamplerCoef()
     c.op = 7
     assert lib.mad_sampler_update(c, 1, 1, None, None, None, None, 1, None, 1, 3, 4, 4, 1, None) != 0
