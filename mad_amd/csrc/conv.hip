@@ -15,8 +15,6 @@
 
 namespace mad {
 
-__device__ __attribute__((aligned(256))) const unsigned char g_zero_page[256] = {0};
-
 struct ConvArgs {
     const void* x1; const void* x2; const void* w; const float* bias; const void* residual; void* y;
     int C1, C2, B, H, W, Cout, ksize, upsample, res_mode;

@@ -7,11 +7,13 @@
 //            tiles of 32x32 per wave) for the body of the network; BN = 32 (WM=4, WN=1, TN=1) for
 //            the last layer, whose 3 output channels are zero-padded to 32 and written as NCHW fp32.
 //   K loop = for each 64-byte channel chunk: the 18x18 input halo of the chunk is staged ONCE into
-//            LDS (through registers: load -> y = silu(x*a+d) -> ds_write; zeros outside the
-//            image), then the 9 taps are 9 K-tiles that read it at shifted addresses.  Weight
-//            tiles (128 rows x 64 bytes per tap) arrive by LDS-DMA, double-buffered; the halo is
-//            double-buffered too and the staging of chunk c+1 is spread over the taps of chunk c
-//            (one 16-byte item per thread per tap) so its VALU work overlaps the MFMAs.
+//            LDS, then the 9 taps are 9 K-tiles that read it at shifted addresses.  Everything that
+//            comes from global memory inside the loop -- halo items, weight tiles (BN rows x 64 bytes
+//            per tap, three buffers), the chunk's GroupNorm coefficients -- arrives by LDS-DMA issued
+//            two K-tiles (weights) to three K-tiles (halo) ahead and is retired with COUNTED vmcnt
+//            waits, so the loop never drains the memory pipeline.  The halo of chunk c+1 is filled
+//            during chunk c, one 16-byte item per thread per tap; each thread then rewrites its own
+//            item in place as y = silu(x*a+d) (zeros outside the image) three taps later.
 //   LDS    = halo pixels at 64-byte pitch, 18 pixels per row, chunk index XOR ((x>>1)&3);
 //            weight rows at 64-byte pitch, chunk index XOR ((row>>2)&3): both make every
 //            ds_read_b128 fragment read bank-conflict free for all nine tap shifts.
@@ -32,12 +34,14 @@ struct HaloArgs {
 constexpr int HT = 16;                 // output tile edge
 constexpr int HS = 18;                 // halo edge
 constexpr int HROW = 64;               // bytes per halo pixel / weight row per K-tile
-constexpr int HALO_BYTES = HS * HS * HROW;          // 20736
-constexpr int HALO_ITEMS = HS * HS * 4;             // 16-byte items per halo chunk: 1296
-constexpr int HALO_ROUNDS = (HALO_ITEMS + 255) / 256;   // 6
+constexpr int HALO_ITEMS = HS * HS * 4;                 // 16-byte items per halo chunk: 1296
+constexpr int HALO_ROUNDS = (HALO_ITEMS + 255) / 256;   // 6 items per thread
+constexpr int HALO_BUF = (HALO_ITEMS + 63) / 64 * 64 * 16;   // 21504: whole wave-instructions
+constexpr int CTAB_BYTES = 1024;       // one DMA instruction's worth; 256 (bf16) / 128 (fp32) bytes used
+constexpr int NWBUF = 3;
 
 template <int BN> constexpr int halo_lds_bytes() {
-    constexpr int stage = 2 * HALO_BYTES + 2 * BN * HROW;
+    constexpr int stage = 2 * HALO_BUF + NWBUF * BN * HROW + 2 * CTAB_BYTES;
     constexpr int epi = 128 * (BN + 4) * 4;
     return stage > epi ? stage : epi;
 }
@@ -52,9 +56,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(HaloArgs a) {
     constexpr int EPI_LD = BN + 4;
     constexpr int VEC = Elem<T>::VEC;
     constexpr int CK = HROW / (int)sizeof(T);      // channels per chunk: 32 (bf16) / 16 (fp32)
+    constexpr int NW = (BN / 16 + 3) / 4;          // weight DMA instructions per wave per K-tile
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* const halo0 = smem;
-    unsigned char* const wt0 = smem + 2 * HALO_BYTES;
+    unsigned char* const wt0 = smem + 2 * HALO_BUF;
+    unsigned char* const ctab0 = wt0 + NWBUF * WTILE_BYTES;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -74,79 +80,82 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(HaloArgs a) {
     const int Ctot = a.C1 + a.C2;
     const int nchunks = Ctot / CK;
 
-    // ---- halo staging assignment: item = tid + 256*j -> (pixel p, 16-byte chunk c4); c4 is fixed per thread
-    const int c4 = tid & 3;
-    int src_pix[HALO_ROUNDS];        // source pixel index (b*Hs + sy)*Ws + sx, or -1 for padding / no item
-    int lds_off[HALO_ROUNDS];
+    // ---- halo staging assignment.  Item = tid + 256*j sits at LDS offset item*16 (lane-linear, as LDS-DMA
+    // requires): pixel p = item>>2, physical chunk tid&3, which holds logical chunk (tid&3) ^ ((hx>>1)&3).
+    // In round 5 only wave 0 has real items; the other waves repeat their round-4 copy so that every wave
+    // issues the same number of memory operations (the counted waits below rely on it).
+    int src_pix[HALO_ROUNDS];        // source pixel index (b*Hs + sy)*Ws + sx, or -1: padding / no item
+    unsigned lchunks = 0;            // 2 bits per round: logical chunk of this thread's item
 #pragma unroll
     for (int j = 0; j < HALO_ROUNDS; ++j) {
-        const int item = tid + 256 * j;
+        const int jj = (j == HALO_ROUNDS - 1 && wave > 0) ? j - 1 : j;
+        const int item = tid + 256 * jj;
         const int p = item >> 2;
         const int hy = p / HS, hx = p - hy * HS;
         const int iy = ty0 - 1 + hy, ix = tx0 - 1 + hx;
         const bool ok = item < HALO_ITEMS && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
         const int sy = a.upsample ? iy >> 1 : iy, sx = a.upsample ? ix >> 1 : ix;
         src_pix[j] = ok ? (b * a.Hs + sy) * a.Ws + sx : -1;
-        lds_off[j] = item < HALO_ITEMS ? p * HROW + ((c4 ^ ((hx >> 1) & 3)) << 4) : -1;
+        lchunks |= (unsigned)((tid & 3) ^ ((hx >> 1) & 3)) << (2 * j);
     }
-
-    auto chunk_src = [&](int cc, const T*& src, int& cs, int& coff) {
+    const unsigned halo_base = lds_addr(halo0);
+    auto dma_item = [&](int cc, int j, int buf) {
         const int c0 = cc * CK;
+        const T* src; int cs, coff;
         if (c0 < a.C1) { src = (const T*)a.x1; cs = a.C1; coff = c0; }
         else { src = (const T*)a.x2; cs = a.C2; coff = c0 - a.C1; }
+        const int lc = (lchunks >> (2 * j)) & 3;
+        const T* p = src + (size_t)max(src_pix[j], 0) * cs + coff + lc * VEC;
+        const void* g = src_pix[j] >= 0 ? (const void*)p : (const void*)g_zero_page;
+        const int jj = (j == HALO_ROUNDS - 1 && wave > 0) ? j - 1 : j;
+        glds16(g, __builtin_amdgcn_readfirstlane(halo_base + buf * HALO_BUF + (256 * jj + 64 * wave) * 16));
     };
-    auto load_item = [&](int cc, int j) -> uint4 {
-        const T* src; int cs, coff;
-        chunk_src(cc, src, cs, coff);
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (src_pix[j] >= 0) v = *reinterpret_cast<const uint4*>(src + (size_t)src_pix[j] * cs + coff + c4 * VEC);
-        return v;
+    // GroupNorm coefficient table of one chunk: CK channels x (a, d) fp32, same copy from every wave
+    const unsigned ctab_base = lds_addr(ctab0);
+    auto dma_coef = [&](int cc, int buf) {
+        constexpr int LANES = CK * 8 / 16;          // 16 (bf16) / 8 (fp32) lanes carry the table
+        const float* g = a.coef + ((size_t)b * Ctot + cc * CK) * 2 + (lane & (LANES - 1)) * 4;
+        glds16(g, __builtin_amdgcn_readfirstlane(ctab_base + buf * CTAB_BYTES));
     };
-    // per-thread GroupNorm coefficients (a, d) of the chunk being staged: this thread's VEC channels
-    float cf_a[VEC], cf_d[VEC];
-    auto load_coef = [&](int cc) {
+    // in-place y = act(x*a + d) of this thread's item j in halo buffer `buf` (zeros for padding)
+    auto xform_item = [&](int j, int buf) {
         if (!FUSE) return;
-        const float* cf = a.coef + ((size_t)b * Ctot + cc * CK + c4 * VEC) * 2;
+        const int item = tid + 256 * j;
+        if (item >= HALO_ITEMS) return;
+        unsigned char* addr = halo0 + buf * HALO_BUF + item * 16;
+        Vec16<T> v; v.raw = *reinterpret_cast<const uint4*>(addr);
+        const int lc = (lchunks >> (2 * j)) & 3;
+        const float* cf = reinterpret_cast<const float*>(ctab0 + buf * CTAB_BYTES) + lc * VEC * 2;
+        float f[VEC]; v.unpack(f);
 #pragma unroll
         for (int i = 0; i < VEC; i += 2) {
             const float4 ad = *reinterpret_cast<const float4*>(cf + 2 * i);
-            cf_a[i] = ad.x; cf_d[i] = ad.y; cf_a[i + 1] = ad.z; cf_d[i + 1] = ad.w;
+            const float t0 = fmaf(f[i], ad.x, ad.y), t1 = fmaf(f[i + 1], ad.z, ad.w);
+            f[i] = a.act ? silu_f(t0) : t0;
+            f[i + 1] = a.act ? silu_f(t1) : t1;
         }
-    };
-    auto put_item = [&](int j, uint4 raw, int buf) {
-        if (lds_off[j] < 0) return;
-        if (FUSE && src_pix[j] >= 0) {
-            Vec16<T> v; v.raw = raw;
-            float f[VEC]; v.unpack(f);
-#pragma unroll
-            for (int i = 0; i < VEC; ++i) {
-                const float t = fmaf(f[i], cf_a[i], cf_d[i]);
-                f[i] = a.act ? silu_f(t) : t;
-            }
-            v.pack(f);
-            raw = v.raw;
-        }
-        *reinterpret_cast<uint4*>(halo0 + buf * HALO_BYTES + lds_off[j]) = raw;
+        v.pack(f);
+        if (src_pix[j] < 0) v.raw = make_uint4(0, 0, 0, 0);
+        *reinterpret_cast<uint4*>(addr) = v.raw;
     };
 
-    // ---- weight tile DMA: one wave-instruction covers 16 rows of 64 bytes; BN/16 instructions per tile
+    // ---- weight tile DMA: one wave-instruction covers 16 rows of 64 bytes; every wave issues NW of them
+    // (for BN < 64 some waves repeat another wave's copy)
     const unsigned wt_base = lds_addr(wt0);
     auto stage_w = [&](int cc, int tap, int buf) {
 #pragma unroll
-        for (int j = 0; j < (BN / 16 + 3) / 4; ++j) {
-            const int blk = j * 4 + wave;                 // 16-row block index
-            if (blk < BN / 16) {
-                const int r = blk * 16 + (lane >> 2);
-                const int lchunk = (lane & 3) ^ ((r >> 2) & 3);
-                const T* g = (const T*)a.w + ((size_t)(n0 + r) * 9 + tap) * Ctot + cc * CK + lchunk * VEC;
-                glds16(g, __builtin_amdgcn_readfirstlane(wt_base + buf * WTILE_BYTES + blk * 16 * HROW));
-            }
+        for (int j = 0; j < NW; ++j) {
+            const int blk = (j * 4 + wave) % (BN / 16);   // 16-row block index
+            const int r = blk * 16 + (lane >> 2);
+            const int lchunk = (lane & 3) ^ ((r >> 2) & 3);
+            const T* g = (const T*)a.w + ((size_t)(n0 + r) * 9 + tap) * Ctot + cc * CK + lchunk * VEC;
+            glds16(g, __builtin_amdgcn_readfirstlane(wt_base + buf * WTILE_BYTES + blk * 16 * HROW));
         }
     };
 
     // ---- fragment addressing
     const int fr = lane & 31, fh = lane >> 5;
-    int a_off[3][2];     // [kx][kk]: byte offset of this lane's A chunk for tile row wm*8, before the (2i+ky) row term
+    int a_off[3][2];     // [kx][kk]: byte offset of this lane's A chunk for this wave's first tile row
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx) {
         const int hx = (fr & 15) + kx;
@@ -170,32 +179,48 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(HaloArgs a) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
-    // ---- prologue: halo of chunk 0 and the first weight tile
+    // ---- prologue: the whole halo of chunk 0, its coefficients, weight tiles 0 and 1
+    if (FUSE) dma_coef(0, 0);
+#pragma unroll
+    for (int j = 0; j < HALO_ROUNDS; ++j) dma_item(0, j, 0);
     stage_w(0, 0, 0);
-    load_coef(0);
+    stage_w(0, 1, 1);
+    dma_wait_all();
+    if (FUSE) __syncthreads();                     // the coefficient table is written by lanes of wave 0..3 alike
 #pragma unroll
-    for (int j = 0; j < HALO_ROUNDS; ++j) put_item(j, load_item(0, j), 0);
+    for (int j = 0; j < HALO_ROUNDS; ++j) xform_item(j, 0);
 
-    int kt = 0;
+    // Operations a wave issues at tap t, in order: NW weight copies (K-tile t+2), the coefficient copy
+    // (t == 0, FUSE), one halo item (t < 6).  Weight tile t was issued first at tap t-2, so at the top of
+    // tap t everything but the operations issued after it may still be in flight:
+    //   N(t) = [coef(t-2) + item(t-2)] + NW + [coef(t-1) + item(t-1)]        (indices mod 9)
     for (int cc = 0; cc < nchunks; ++cc) {
-        const unsigned char* halo = halo0 + (cc & 1) * HALO_BYTES;
-        const bool more = cc + 1 < nchunks;
-        uint4 pending = make_uint4(0, 0, 0, 0);
+        const unsigned char* halo = halo0 + (cc & 1) * HALO_BUF;
+        const int nb = (cc + 1) & 1;                              // halo / table buffer of the next chunk
+        const int ccn = cc + 1 < nchunks ? cc + 1 : cc;           // last chunk: harmless restaging of itself
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap, ++kt) {
+        for (int tap = 0; tap < 9; ++tap) {
             const int ky = tap / 3, kx = tap % 3;
-            // weight tile kt and (at tap 0) the halo of this chunk are complete and visible after this
-            // barrier; it also means every wave has finished the K-tile that last used the buffers
-            // about to be refilled
-            dma_wait_all();
+            constexpr int C0 = FUSE ? 1 : 0;
+            const int t1 = (tap + 8) % 9, t2 = (tap + 7) % 9;
+            const int nwait = ((t2 == 0 ? C0 : 0) + (t2 < HALO_ROUNDS ? 1 : 0)) + NW +
+                              ((t1 == 0 ? C0 : 0) + (t1 < HALO_ROUNDS ? 1 : 0));
+            // weight tile `tap` has landed; after the barrier it and (at tap 0) the finished halo of this
+            // chunk are visible to every wave, and every wave is done with the buffers refilled below
+            switch (nwait) {
+                case 1: dma_wait_upto<1>(); break;
+                case 2: dma_wait_upto<2>(); break;
+                case 3: dma_wait_upto<3>(); break;
+                case 4: dma_wait_upto<4>(); break;
+                case 5: dma_wait_upto<5>(); break;
+                default: dma_wait_upto<6>(); break;
+            }
             __syncthreads();
-            if (tap < 8) stage_w(cc, tap + 1, (kt + 1) & 1);
-            else if (more) stage_w(cc + 1, 0, (kt + 1) & 1);
-            // staging of the next chunk's halo, one item per tap: issue the load of item `tap`, finish item `tap-1`
-            uint4 fresh = make_uint4(0, 0, 0, 0);
-            if (more && tap == 0) load_coef(cc + 1);
-            if (more && tap < HALO_ROUNDS) fresh = load_item(cc + 1, tap);
-            const unsigned char* wt = wt0 + (kt & 1) * WTILE_BYTES;
+            if (tap + 2 < 9) stage_w(cc, tap + 2, (tap + 2) % NWBUF);
+            else stage_w(ccn, tap + 2 - 9, (tap + 2) % NWBUF);
+            if (FUSE && tap == 0) dma_coef(ccn, nb);
+            if (tap < HALO_ROUNDS) dma_item(ccn, tap, nb);
+            const unsigned char* wt = wt0 + (tap % NWBUF) * WTILE_BYTES;
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
                 uint4 af[TM], bfr[TN];
@@ -209,10 +234,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(HaloArgs a) {
 #pragma unroll
                     for (int jn = 0; jn < TN; ++jn) mma_chunk<T>(acc[i][jn], af[i], bfr[jn]);
             }
-            if (more && tap >= 1 && tap <= HALO_ROUNDS) put_item(tap - 1, pending, (cc + 1) & 1);
-            pending = fresh;
+            // item tap-3 of the next chunk was issued three taps ago, before weight tile `tap`: it has landed
+            if (tap >= 3 && tap - 3 < HALO_ROUNDS) xform_item(tap - 3, nb);
         }
     }
+    dma_wait_all();      // the restaging copies of the last chunk must land before LDS is reused below
 
     // ---- epilogue, one half tile (8 tile rows = 128 pixels) at a time
     float* ctile = reinterpret_cast<float*>(smem);

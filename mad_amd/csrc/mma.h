@@ -52,6 +52,16 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_wave_base)
 
 __device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
+// Wait until at most N of this wave's vector-memory operations (LDS-DMA included) are outstanding;
+// they retire in issue order, so everything older than the N youngest has landed.
+template <int N> __device__ __forceinline__ void dma_wait_upto() {
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit field");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// Source of LDS-DMA copies that must deliver zeros (conv padding, rows past the end).
+__device__ __attribute__((aligned(256))) const unsigned char g_zero_page[256] = {0};
+
 // Byte address inside the workgroup's LDS allocation of a pointer into __shared__ memory.
 __device__ __forceinline__ unsigned lds_addr(const void* p) {
     return (unsigned)(size_t)(__attribute__((address_space(3))) const void*)p;
