@@ -24,3 +24,18 @@ def shard_list(items: Sequence[T], world_size: int, rank: int) -> Tuple[List[T],
     """-> (this rank's items, index offset of its first item)."""
     lo, hi = shard_bounds(len(items), world_size, rank)
     return list(items[lo:hi]), lo
+
+
+def job_throughput(local_items: int, local_seconds: float, device=None):
+    """Whole-job items/s for one-process-per-GPU runs: items summed over ranks divided by the slowest
+    rank's time.  Uses the default process group when one is initialised (RCCL on GPUs, gloo on CPU);
+    a single process needs none.  Returns (items_total, seconds_max, items_per_second)."""
+    import torch
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        t = torch.tensor([float(local_seconds)], dtype=torch.float64, device=device)
+        n = torch.tensor([float(local_items)], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(n, op=dist.ReduceOp.SUM)
+        local_seconds, local_items = float(t.item()), int(n.item())
+    return local_items, local_seconds, local_items / local_seconds

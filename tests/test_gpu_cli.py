@@ -1,0 +1,39 @@
+"""The generate_translation entry point end to end on tiny synthetic files (GPU only)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import REPO
+
+pytestmark = pytest.mark.gpu
+
+
+def test_generate_translation_cli(tmp_path):
+    from PIL import Image
+    import generate_translation as gt
+    from mad_amd.synthetic import synthetic_faces, synthetic_parsing_map
+    img_dir, par_dir = tmp_path / "images", tmp_path / "parsing"
+    img_dir.mkdir(); par_dir.mkdir()
+    faces = synthetic_faces(3, 16, seed=3)
+    names = []
+    for i in range(3):
+        arr = ((faces[i].permute(1, 2, 0).numpy() * 0.5 + 0.5) * 255).astype("uint8")
+        Image.fromarray(arr).save(img_dir / f"f{i}.png")
+        Image.fromarray(synthetic_parsing_map(16, seed=i).numpy()).save(par_dir / f"f{i}.png")
+        names.append(f"f{i}.png")
+    names.append("missing.png")                                   # a broken entry must not stop the run
+    (tmp_path / "list.txt").write_text("\n".join(names) + "\n")
+    out = tmp_path / "out"
+    argv = ["--config", os.path.join(REPO, "configs", "model_tiny.yaml"), "--save-folder", str(out),
+            "--source-root", str(img_dir), "--source-list", str(tmp_path / "list.txt"), "--source-label", "0",
+            "--target-label", "1", "--num-of-step", "6", "--batch", "2"]
+    gt.main(argv)
+    made = sorted(os.listdir(out))
+    assert made == ["pred_0.png", "pred_1.png", "pred_2.png"]
+    first = np.array(Image.open(out / "pred_0.png"))
+    assert first.shape == (16, 16, 3)
+    stamp = os.path.getmtime(out / "pred_0.png")
+    gt.main(argv)                                                 # second run skips what exists
+    assert os.path.getmtime(out / "pred_0.png") == stamp

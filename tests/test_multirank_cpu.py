@@ -1,0 +1,47 @@
+"""The N>1 path on CPU: two gloo ranks shard a list as the reference does, with no data-path
+collective; only the timing reduction (max over ranks) and the item count use the process group."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from mad_amd.shard import job_throughput, shard_list
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, items, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mine, offset = shard_list(items, world, rank)
+    # "translate" the shard: independent items, written under their global index
+    for i, it in enumerate(mine):
+        with open(os.path.join(out_dir, f"pred_{i + offset}.txt"), "w") as f:
+            f.write(str(it * 2))
+    dist.barrier()
+    total, secs, rate = job_throughput(len(mine), 1.0 + rank, None)     # rank 1 is "slower"
+    assert total == len(items) and secs == float(world) and abs(rate - len(items) / world) < 1e-9
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_two_ranks_cover_the_list(tmp_path):
+    items = list(range(7))
+    mp.spawn(_worker, args=(2, _free_port(), items, str(tmp_path)), nprocs=2, join=True)
+    for i in items:
+        assert open(tmp_path / f"pred_{i}.txt").read() == str(i * 2)
+    assert len(list(tmp_path.iterdir())) == len(items)
+
+
+def test_single_process_needs_no_group():
+    assert job_throughput(8, 2.0) == (8, 2.0, 4.0)
