@@ -12,6 +12,8 @@
 //   conv_in_kernel     first layer (Cin = 3, NCHW fp32 in, NHWC out): direct, bandwidth bound.
 //   conv_out_kernel    last layer (Cout = 3, NHWC in, NCHW fp32 out): direct, bandwidth bound.
 #include "mma.h"
+#include <cstdlib>
+#include <string>
 
 namespace mad {
 
@@ -23,21 +25,26 @@ struct ConvArgs {
     int mtiles, ntiles;
 };
 
-constexpr int BM = 128;
 constexpr int ROWB = 128;   // bytes per LDS row = one K-tile of one operand row
 
-template <int BN> constexpr int conv_lds_bytes() {
-    constexpr int stage = 2 * (BM + BN) * ROWB;
+template <int BM, int BN, int NST> constexpr int conv_lds_bytes() {
+    constexpr int stage = NST * (BM + BN) * ROWB;
     constexpr int epi = BM * (BN + 4) * 4;
     return stage > epi ? stage : epi;
 }
 
-template <typename T, int BN>
+// BM x BN block tile, NST K-tile buffers in a ring.  Tile kt+NST-1 is requested while tile kt is
+// multiplied; a wave waits only until its own copies of tile kt have landed (they retire in issue
+// order), and the barrier that follows both publishes tile kt and frees the buffer of tile kt-1.
+template <typename T, int BM, int BN, int NST>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
     constexpr int VEC = Elem<T>::VEC;             // elements per 16-byte chunk
     constexpr int CK = ROWB / (int)sizeof(T);     // channels per K-tile
-    constexpr int TN = BN / 64;                   // 32-wide accumulator tiles per wave along n
+    constexpr int TM = BM / 64, TN = BN / 64;     // 32x32 accumulator tiles per wave
+    constexpr int APW = BM / 32, BPW = BN / 32;   // 1-KiB copy instructions per wave per K-tile
+    constexpr int PPW = APW + BPW;
     constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB;
+    static_assert((NST - 2) * PPW < 64, "outstanding copies must fit the vmcnt field");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -60,11 +67,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
     const int pad = a.ksize >> 1;
     const int HW = a.H * a.W;
 
-    // ---- per-thread DMA assignment: instruction j of this wave covers rows (j*4+wave)*8 .. +7
+    // ---- per-thread copy assignment: instruction j of this wave covers rows (j*4+wave)*8 .. +7
     const int lrow = lane >> 3, pchunk = lane & 7;
-    int a_oy[4], a_ox[4], a_b[4];
+    int a_oy[APW], a_ox[APW], a_b[APW];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < APW; ++j) {
         const int m = m0 + (j * 4 + wave) * 8 + lrow;
         if (m < a.M) {
             const int b = m / HW, rem = m - b * HW;
@@ -85,7 +92,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
         const unsigned abuf = smem_base + buf * (A_BYTES + B_BYTES);
         const unsigned bbuf = abuf + A_BYTES;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < APW; ++j) {
             const int r = (j * 4 + wave) * 8 + lrow;
             const int lchunk = pchunk ^ ((r >> 1) & 7);
             const int iy = a_oy[j] + ky - pad, ix = a_ox[j] + kx - pad;
@@ -99,7 +106,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
             glds16(g, __builtin_amdgcn_readfirstlane(abuf + (j * 4 + wave) * 8 * ROWB));
         }
 #pragma unroll
-        for (int j = 0; j < BN / 32; ++j) {
+        for (int j = 0; j < BPW; ++j) {
             const int r = (j * 4 + wave) * 8 + lrow;
             const int lchunk = pchunk ^ ((r >> 1) & 7);
             const T* g = (const T*)a.w + ((size_t)(n0 + r) * ntaps + tap) * Ctot + c0 + lchunk * VEC;
@@ -107,30 +114,31 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
         }
     };
 
-    f32x16 acc[2][TN];
+    f32x16 acc[TM][TN];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
     const int frow = lane & 31, fh = lane >> 5;
-    stage(0, 0);
+    for (int p = 0; p < NST - 1 && p < nk; ++p) stage(p, p);
+    int buf = 0, nbuf = NST - 1;                 // buffer of tile kt, buffer tile kt+NST-1 goes to
     for (int kt = 0; kt < nk; ++kt) {
-        // every wave waits for its own copies of tile kt, then the barrier publishes the tile and
-        // also means every wave is done reading the buffer tile kt+1 is about to overwrite
-        dma_wait_all();
+        // tiles kt+1 .. kt+NST-2 may still be in flight; near the end fewer were requested
+        if (kt + NST - 2 < nk) dma_wait_upto<(NST - 2) * PPW>();
+        else dma_wait_all();
         __syncthreads();
-        if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
-        const unsigned char* abuf = smem + (kt & 1) * (A_BYTES + B_BYTES);
+        if (kt + NST - 1 < nk) stage(kt + NST - 1, nbuf);
+        const unsigned char* abuf = smem + buf * (A_BYTES + B_BYTES);
         const unsigned char* bbuf = abuf + A_BYTES;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
-            uint4 af[2], bfr[TN];
+            uint4 af[TM], bfr[TN];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int r = wm * 64 + i * 32 + frow;
+            for (int i = 0; i < TM; ++i) {
+                const int r = wm * (BM / 2) + i * 32 + frow;
                 af[i] = *reinterpret_cast<const uint4*>(abuf + r * ROWB + (((2 * kk + fh) ^ ((r >> 1) & 7)) << 4));
             }
 #pragma unroll
@@ -139,36 +147,51 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
                 bfr[j] = *reinterpret_cast<const uint4*>(bbuf + r * ROWB + (((2 * kk + fh) ^ ((r >> 1) & 7)) << 4));
             }
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) mma_chunk<T>(acc[i][j], af[i], bfr[j]);
         }
+        buf = buf + 1 == NST ? 0 : buf + 1;
+        nbuf = nbuf + 1 == NST ? 0 : nbuf + 1;
     }
 
     // ---- epilogue: fp32 tile -> LDS -> coalesced 16-byte stores with bias / residual
+    constexpr int CPR = BN / VEC;            // 16-byte output chunks per tile row
+    constexpr int RPP = 256 / CPR;           // rows per pass
+    constexpr int NPASS = BM / RPP;
+    const int er = tid / CPR, ec = (tid % CPR) * VEC;
+    const T* res = (const T*)a.residual;
+    T* y = (T*)a.y;
+    // residual rows are requested before the tile hand-over so their latency overlaps it
+    constexpr int NPRE = NPASS <= 8 ? NPASS : 8;
+    uint4 rpre[NPRE];
+    if (a.res_mode == MAD_RES_SAME) {
+#pragma unroll
+        for (int k = 0; k < NPRE; ++k) {
+            const int m = min(m0 + er + k * RPP, a.M - 1);
+            rpre[k] = *reinterpret_cast<const uint4*>(res + (size_t)m * a.Cout + n0 + ec);
+        }
+    }
     __syncthreads();
     float* ctile = reinterpret_cast<float*>(smem);
     constexpr int CLD = BN + 4;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int r = wm * 64 + i * 32 + acc_row(e, lane);
+                const int r = wm * (BM / 2) + i * 32 + acc_row(e, lane);
                 const int c = wn * (BN / 2) + j * 32 + (lane & 31);
                 ctile[r * CLD + c] = acc[i][j][e];
             }
     __syncthreads();
-    constexpr int CPR = BN / VEC;            // 16-byte output chunks per tile row
-    constexpr int RPP = 256 / CPR;           // rows per pass
-    const int er = tid / CPR, ec = (tid % CPR) * VEC;
     float bias_v[VEC];
 #pragma unroll
     for (int i = 0; i < VEC; ++i) bias_v[i] = a.bias ? a.bias[n0 + ec + i] : 0.0f;
-    const T* res = (const T*)a.residual;
-    T* y = (T*)a.y;
-    for (int r = er; r < BM; r += RPP) {
+#pragma unroll
+    for (int k = 0; k < NPASS; ++k) {
+        const int r = er + k * RPP;
         const int m = m0 + r;
         if (m >= a.M) break;
         float v[VEC];
@@ -179,7 +202,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
             v[i + 2] = t.z + bias_v[i + 2]; v[i + 3] = t.w + bias_v[i + 3];
         }
         if (a.res_mode == MAD_RES_SAME) {
-            Vec16<T> rv; rv.load(res + (size_t)m * a.Cout + n0 + ec);
+            Vec16<T> rv;
+            if (k < NPRE) rv.raw = rpre[k < NPRE ? k : 0];
+            else rv.load(res + (size_t)m * a.Cout + n0 + ec);
             float f[VEC]; rv.unpack(f);
 #pragma unroll
             for (int i = 0; i < VEC; ++i) v[i] += f[i];
@@ -318,16 +343,37 @@ __global__ __launch_bounds__(256) void conv_out_kernel(const T* __restrict__ x, 
     for (int co = 0; co < Cout; ++co) y[((size_t)(b * Cout + co) * H + oy) * W + ox] = acc[co] + bias[co];
 }
 
-template <typename T, int BN> static int launch_igemm(const ConvArgs& a, hipStream_t s) {
-    constexpr int lds = conv_lds_bytes<BN>();
+template <typename T, int BM, int BN, int NST> static int launch_igemm(ConvArgs a, hipStream_t s) {
+    constexpr int lds = conv_lds_bytes<BM, BN, NST>();
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<T, BN>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        MAD_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<T, BM, BN, NST>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess,
+                    "mad_conv2d: cannot raise the dynamic LDS limit to %d", lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv_igemm_kernel<T, BN>), dim3(a.mtiles * a.ntiles), dim3(256), lds, s, a);
+    a.mtiles = (a.M + BM - 1) / BM;
+    a.ntiles = a.Cout / BN;
+    hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, NST>), dim3(a.mtiles * a.ntiles), dim3(256), lds, s, a);
     return check_launch("mad_conv2d");
+}
+
+// Tile choice: 128x128 tiles when they fill the chip at least once; otherwise 64x64 tiles with a
+// deeper ring, which quadruples the number of workgroups of the small late-stage layers.
+template <typename T> static int dispatch_igemm(const ConvArgs& a, hipStream_t s) {
+    const char* force = getenv("MAD_IGEMM_TILE");      // tuning aid: "128x128x2", "64x64x4", ...
+    const std::string f = force ? force : "";
+    const int big_blocks = ((a.M + 127) / 128) * (a.Cout / 128);
+    const bool wide = a.Cout % 128 == 0;
+    if (f == "128x128x2" && wide) return launch_igemm<T, 128, 128, 2>(a, s);
+    if (f == "128x128x3" && wide) return launch_igemm<T, 128, 128, 3>(a, s);
+    if (f == "128x64x3") return launch_igemm<T, 128, 64, 3>(a, s);
+    if (f == "128x64x2") return launch_igemm<T, 128, 64, 2>(a, s);
+    if (f == "64x64x4") return launch_igemm<T, 64, 64, 4>(a, s);
+    if (f == "64x128x3" && wide) return launch_igemm<T, 64, 128, 3>(a, s);
+    if (wide && big_blocks >= 256) return launch_igemm<T, 128, 128, 2>(a, s);
+    if (!wide && ((a.M + 127) / 128) * (a.Cout / 64) >= 256) return launch_igemm<T, 128, 64, 2>(a, s);
+    return launch_igemm<T, 64, 64, 4>(a, s);
 }
 
 }  // namespace mad
@@ -353,12 +399,8 @@ extern "C" int mad_conv2d(const void* x1, int C1, const void* x2, int C2, const 
     a.C1 = C1; a.C2 = C2; a.B = B; a.H = H; a.W = W; a.Cout = Cout; a.ksize = ksize; a.upsample = upsample;
     a.res_mode = res_mode; a.M = B * H * W;
     a.Hs = upsample ? H / 2 : H; a.Ws = upsample ? W / 2 : W;
-    a.mtiles = (a.M + BM - 1) / BM;
-    const bool wide = (Cout % 128 == 0);
-    a.ntiles = Cout / (wide ? 128 : 64);
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == MAD_BF16) return wide ? launch_igemm<bf16_t, 128>(a, s) : launch_igemm<bf16_t, 64>(a, s);
-    return wide ? launch_igemm<float, 128>(a, s) : launch_igemm<float, 64>(a, s);
+    return dtype == MAD_BF16 ? dispatch_igemm<bf16_t>(a, s) : dispatch_igemm<float>(a, s);
 }
 
 extern "C" int mad_conv_in(const float* x, const float* w, const float* bias, void* y, int dtype, int B, int Cin,

@@ -21,6 +21,7 @@
 //            residual; per-channel sum / sum of squares of the stored values go to a
 //            (B, tiles, Cout, 2) slab in a fixed order (deterministic).
 #include "mma.h"
+#include <cstdlib>
 
 namespace mad {
 
@@ -35,28 +36,54 @@ constexpr int HT = 16;                 // output tile edge
 constexpr int HS = 18;                 // halo edge
 constexpr int HROW = 64;               // bytes per halo pixel / weight row per K-tile
 constexpr int HALO_ITEMS = HS * HS * 4;                 // 16-byte items per halo chunk: 1296
-constexpr int HALO_ROUNDS = (HALO_ITEMS + 255) / 256;   // 6 items per thread
 constexpr int HALO_BUF = (HALO_ITEMS + 63) / 64 * 64 * 16;   // 21504: whole wave-instructions
 constexpr int CTAB_BYTES = 1024;       // one DMA instruction's worth; 256 (bf16) / 128 (fp32) bytes used
 constexpr int NWBUF = 3;
 
+#ifdef MAD_HALO_STAMPS
+// Timing aid (separate build only): cycle stamps of every wave of one workgroup for the taps of its
+// second channel chunk, [wave][tap][point]; points: tap top, copies landed, barrier passed,
+// MFMAs issued, transform done.
+__device__ unsigned g_stamps[8 * 9 * 8];
+#define MAD_STAMP(pt)                                                                      \
+    if (stamp_on && cc == 1) {                                                             \
+        const unsigned t_ = (unsigned)__builtin_readcyclecounter();                        \
+        if (lane == 0) stamp_lds[(wave * 9 + tap) * 8 + (pt)] = t_;                        \
+    }
+#define MAD_STAMP_PHASE(k)                                                                 \
+    if (stamp_on) {                                                                        \
+        const unsigned t_ = (unsigned)__builtin_readcyclecounter();                        \
+        if (lane == 0) stamp_lds[(wave * 9 + (k)) * 8 + 5] = t_;                           \
+    }
+#else
+#define MAD_STAMP(pt)
+#define MAD_STAMP_PHASE(k)
+#endif
+
 template <int BN> constexpr int halo_lds_bytes() {
     constexpr int stage = 2 * HALO_BUF + NWBUF * BN * HROW + 2 * CTAB_BYTES;
     constexpr int epi = 128 * (BN + 4) * 4;
+#ifdef MAD_HALO_STAMPS
+    return (stage > epi ? stage : epi) + 4096;
+#else
     return stage > epi ? stage : epi;
+#endif
 }
 
 // OUT_NCHW: write the first a.Cout (<= BN) channels as NCHW fp32 with bias (last layer).
 template <typename T, bool FUSE, int WM, int WN, int TN, bool OUT_NCHW>
-__global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(HaloArgs a) {
-    static_assert(WM * WN == 4, "4 waves");
+__global__ __launch_bounds__(64 * WM * WN, WM * WN / 2) void conv3x3_halo_kernel(HaloArgs a) {
+    constexpr int NWAVES = WM * WN, NT = 64 * NWAVES;
+    static_assert(NWAVES == 4 || NWAVES == 8, "4 or 8 waves");
+    constexpr int HALO_ROUNDS = (HALO_ITEMS + NT - 1) / NT;   // items per thread: 6 (4 waves) / 3 (8 waves)
+    static_assert(HALO_ROUNDS <= 6, "one halo item per tap, transformed three taps later");
     constexpr int BN = WN * TN * 32;
     constexpr int TM = 8 / WM;                     // 32-pixel accumulator tiles per wave (2 tile rows each)
     constexpr int WTILE_BYTES = BN * HROW;
     constexpr int EPI_LD = BN + 4;
     constexpr int VEC = Elem<T>::VEC;
     constexpr int CK = HROW / (int)sizeof(T);      // channels per chunk: 32 (bf16) / 16 (fp32)
-    constexpr int NW = (BN / 16 + 3) / 4;          // weight DMA instructions per wave per K-tile
+    constexpr int NW = (BN / 16 + NWAVES - 1) / NWAVES;   // weight DMA instructions per wave per K-tile
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* const halo0 = smem;
     unsigned char* const wt0 = smem + 2 * HALO_BUF;
@@ -79,17 +106,27 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(HaloArgs a) {
 
     const int Ctot = a.C1 + a.C2;
     const int nchunks = Ctot / CK;
+#ifdef MAD_HALO_STAMPS
+    unsigned* const stamp_lds = reinterpret_cast<unsigned*>(smem + halo_lds_bytes<BN>() - 4096);
+    const bool stamp_on = blockIdx.x == gridDim.x / 2 + 3;
+    const int lane_ = threadIdx.x & 63, wave_ = threadIdx.x >> 6;
+    if (stamp_on) {
+        const unsigned t_ = (unsigned)__builtin_readcyclecounter();
+        if (lane_ == 0) stamp_lds[(wave_ * 9 + 0) * 8 + 5] = t_;
+    }
+#endif
 
-    // ---- halo staging assignment.  Item = tid + 256*j sits at LDS offset item*16 (lane-linear, as LDS-DMA
+    // ---- halo staging assignment.  Item = tid + NT*j sits at LDS offset item*16 (lane-linear, as LDS-DMA
     // requires): pixel p = item>>2, physical chunk tid&3, which holds logical chunk (tid&3) ^ ((hx>>1)&3).
-    // In round 5 only wave 0 has real items; the other waves repeat their round-4 copy so that every wave
-    // issues the same number of memory operations (the counted waits below rely on it).
+    // In the last round only the first wave(s) have real items; the others repeat their previous copy so
+    // that every wave issues the same number of memory operations (the counted waits below rely on it).
+    const bool last_round_real = NT * (HALO_ROUNDS - 1) + 64 * wave < HALO_BUF / 16;
     int src_pix[HALO_ROUNDS];        // source pixel index (b*Hs + sy)*Ws + sx, or -1: padding / no item
     unsigned lchunks = 0;            // 2 bits per round: logical chunk of this thread's item
 #pragma unroll
     for (int j = 0; j < HALO_ROUNDS; ++j) {
-        const int jj = (j == HALO_ROUNDS - 1 && wave > 0) ? j - 1 : j;
-        const int item = tid + 256 * jj;
+        const int jj = (j == HALO_ROUNDS - 1 && !last_round_real) ? j - 1 : j;
+        const int item = tid + NT * jj;
         const int p = item >> 2;
         const int hy = p / HS, hx = p - hy * HS;
         const int iy = ty0 - 1 + hy, ix = tx0 - 1 + hx;
@@ -107,8 +144,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(HaloArgs a) {
         const int lc = (lchunks >> (2 * j)) & 3;
         const T* p = src + (size_t)max(src_pix[j], 0) * cs + coff + lc * VEC;
         const void* g = src_pix[j] >= 0 ? (const void*)p : (const void*)g_zero_page;
-        const int jj = (j == HALO_ROUNDS - 1 && wave > 0) ? j - 1 : j;
-        glds16(g, __builtin_amdgcn_readfirstlane(halo_base + buf * HALO_BUF + (256 * jj + 64 * wave) * 16));
+        const int jj = (j == HALO_ROUNDS - 1 && !last_round_real) ? j - 1 : j;
+        glds16(g, __builtin_amdgcn_readfirstlane(halo_base + buf * HALO_BUF + (NT * jj + 64 * wave) * 16));
     };
     // GroupNorm coefficient table of one chunk: CK channels x (a, d) fp32, same copy from every wave
     const unsigned ctab_base = lds_addr(ctab0);
@@ -120,8 +157,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(HaloArgs a) {
     // in-place y = act(x*a + d) of this thread's item j in halo buffer `buf` (zeros for padding)
     auto xform_item = [&](int j, int buf) {
         if (!FUSE) return;
-        const int item = tid + 256 * j;
-        if (item >= HALO_ITEMS) return;
+        const int item = tid + NT * j;
+        if (j == HALO_ROUNDS - 1 && item >= HALO_ITEMS) return;     // only the last round is partial
         unsigned char* addr = halo0 + buf * HALO_BUF + item * 16;
         Vec16<T> v; v.raw = *reinterpret_cast<const uint4*>(addr);
         const int lc = (lchunks >> (2 * j)) & 3;
@@ -145,7 +182,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(HaloArgs a) {
     auto stage_w = [&](int cc, int tap, int buf) {
 #pragma unroll
         for (int j = 0; j < NW; ++j) {
-            const int blk = (j * 4 + wave) % (BN / 16);   // 16-row block index
+            const int blk = (j * NWAVES + wave) % (BN / 16);   // 16-row block index
             const int r = blk * 16 + (lane >> 2);
             const int lchunk = (lane & 3) ^ ((r >> 2) & 3);
             const T* g = (const T*)a.w + ((size_t)(n0 + r) * 9 + tap) * Ctot + cc * CK + lchunk * VEC;
@@ -194,6 +231,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(HaloArgs a) {
     // (t == 0, FUSE), one halo item (t < 6).  Weight tile t was issued first at tap t-2, so at the top of
     // tap t everything but the operations issued after it may still be in flight:
     //   N(t) = [coef(t-2) + item(t-2)] + NW + [coef(t-1) + item(t-1)]        (indices mod 9)
+    MAD_STAMP_PHASE(1)
     for (int cc = 0; cc < nchunks; ++cc) {
         const unsigned char* halo = halo0 + (cc & 1) * HALO_BUF;
         const int nb = (cc + 1) & 1;                              // halo / table buffer of the next chunk
@@ -207,6 +245,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(HaloArgs a) {
                               ((t1 == 0 ? C0 : 0) + (t1 < HALO_ROUNDS ? 1 : 0));
             // weight tile `tap` has landed; after the barrier it and (at tap 0) the finished halo of this
             // chunk are visible to every wave, and every wave is done with the buffers refilled below
+            MAD_STAMP(0)
             switch (nwait) {
                 case 1: dma_wait_upto<1>(); break;
                 case 2: dma_wait_upto<2>(); break;
@@ -215,30 +254,47 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(HaloArgs a) {
                 case 5: dma_wait_upto<5>(); break;
                 default: dma_wait_upto<6>(); break;
             }
+            MAD_STAMP(1)
             __syncthreads();
+            MAD_STAMP(2)
+            const unsigned char* wt = wt0 + (tap % NWBUF) * WTILE_BYTES;
+            // The first fragments are requested before the copies are issued (the issue time covers
+            // the LDS latency), and the copies are spread between groups of MFMAs.
+            uint4 af[2][TM], bfr[2][TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                af[0][i] = *reinterpret_cast<const uint4*>(halo + a_off[kx][0] + (2 * i + ky) * HS * HROW);
+#pragma unroll
+            for (int jn = 0; jn < TN; ++jn) bfr[0][jn] = *reinterpret_cast<const uint4*>(wt + b_off[jn][0]);
             if (tap + 2 < 9) stage_w(cc, tap + 2, (tap + 2) % NWBUF);
             else stage_w(ccn, tap + 2 - 9, (tap + 2) % NWBUF);
+#pragma unroll
+            for (int i = 0; i < TM / 2; ++i)
+#pragma unroll
+                for (int jn = 0; jn < TN; ++jn) mma_chunk<T>(acc[i][jn], af[0][i], bfr[0][jn]);
             if (FUSE && tap == 0) dma_coef(ccn, nb);
             if (tap < HALO_ROUNDS) dma_item(ccn, tap, nb);
-            const unsigned char* wt = wt0 + (tap % NWBUF) * WTILE_BYTES;
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                uint4 af[TM], bfr[TN];
+            for (int i = 0; i < TM; ++i)
+                af[1][i] = *reinterpret_cast<const uint4*>(halo + a_off[kx][1] + (2 * i + ky) * HS * HROW);
 #pragma unroll
-                for (int i = 0; i < TM; ++i)
-                    af[i] = *reinterpret_cast<const uint4*>(halo + a_off[kx][kk] + (2 * i + ky) * HS * HROW);
+            for (int jn = 0; jn < TN; ++jn) bfr[1][jn] = *reinterpret_cast<const uint4*>(wt + b_off[jn][1]);
 #pragma unroll
-                for (int jn = 0; jn < TN; ++jn) bfr[jn] = *reinterpret_cast<const uint4*>(wt + b_off[jn][kk]);
+            for (int i = TM / 2; i < TM; ++i)
 #pragma unroll
-                for (int i = 0; i < TM; ++i)
+                for (int jn = 0; jn < TN; ++jn) mma_chunk<T>(acc[i][jn], af[0][i], bfr[0][jn]);
 #pragma unroll
-                    for (int jn = 0; jn < TN; ++jn) mma_chunk<T>(acc[i][jn], af[i], bfr[jn]);
-            }
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int jn = 0; jn < TN; ++jn) mma_chunk<T>(acc[i][jn], af[1][i], bfr[1][jn]);
+            MAD_STAMP(3)
             // item tap-3 of the next chunk was issued three taps ago, before weight tile `tap`: it has landed
             if (tap >= 3 && tap - 3 < HALO_ROUNDS) xform_item(tap - 3, nb);
+            MAD_STAMP(4)
         }
     }
     dma_wait_all();      // the restaging copies of the last chunk must land before LDS is reused below
+    MAD_STAMP_PHASE(2)
 
     // ---- epilogue, one half tile (8 tile rows = 128 pixels) at a time
     float* ctile = reinterpret_cast<float*>(smem);
@@ -270,15 +326,29 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(HaloArgs a) {
         return;
     } else {
     constexpr int CPR = BN / VEC;            // 16-byte chunks per output row
-    constexpr int RPP = 256 / CPR;           // rows per pass
+    constexpr int RPP = NT / CPR;            // rows per pass
     const int er = tid / CPR, ec = (tid % CPR) * VEC;
     float bias_v[VEC], ssum[VEC], ssq[VEC];
 #pragma unroll
     for (int i = 0; i < VEC; ++i) { bias_v[i] = a.bias ? a.bias[n0 + ec + i] : 0.0f; ssum[i] = 0.0f; ssq[i] = 0.0f; }
     const T* res = (const T*)a.residual;
     T* y = (T*)a.y;
+    constexpr int RPT = 128 / RPP;           // rows per thread per half tile
 #pragma unroll 1
     for (int half = 0; half < 2; ++half) {
+        // residual rows of this half are requested first: their latency overlaps the tile hand-over
+        uint4 rpre[RPT];
+        if (a.res_mode == MAD_RES_SAME || a.res_mode == MAD_RES_UP) {
+#pragma unroll
+            for (int k = 0; k < RPT; ++k) {
+                const int r = er + k * RPP;
+                const int oy = ty0 + half * 8 + (r >> 4), ox = tx0 + (r & 15);
+                const size_t rp = a.res_mode == MAD_RES_SAME
+                                      ? ((size_t)b * a.H + oy) * a.W + ox
+                                      : ((size_t)b * (a.H >> 1) + (oy >> 1)) * (a.W >> 1) + (ox >> 1);
+                rpre[k] = *reinterpret_cast<const uint4*>(res + rp * a.Cout + n0 + ec);
+            }
+        }
         __syncthreads();
         if ((wm * ROWS_PER_WAVE) / 128 == half) {
             const int rbase = wm * ROWS_PER_WAVE - half * 128;
@@ -292,7 +362,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(HaloArgs a) {
                             acc[i][jn][e];
         }
         __syncthreads();
-        for (int r = er; r < 128; r += RPP) {
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) {
+            const int r = er + k * RPP;
             const int oy = ty0 + half * 8 + (r >> 4), ox = tx0 + (r & 15);
             const size_t m = ((size_t)b * a.H + oy) * a.W + ox;
             float v[VEC];
@@ -302,14 +374,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(HaloArgs a) {
                 v[i] = t.x + bias_v[i]; v[i + 1] = t.y + bias_v[i + 1];
                 v[i + 2] = t.z + bias_v[i + 2]; v[i + 3] = t.w + bias_v[i + 3];
             }
-            if (a.res_mode == MAD_RES_SAME) {
-                Vec16<T> rv; rv.load(res + m * a.Cout + n0 + ec);
-                float f[VEC]; rv.unpack(f);
-#pragma unroll
-                for (int i = 0; i < VEC; ++i) v[i] += f[i];
-            } else if (a.res_mode == MAD_RES_UP) {
-                const size_t rp = ((size_t)b * (a.H >> 1) + (oy >> 1)) * (a.W >> 1) + (ox >> 1);
-                Vec16<T> rv; rv.load(res + rp * a.Cout + n0 + ec);
+            if (a.res_mode == MAD_RES_SAME || a.res_mode == MAD_RES_UP) {
+                Vec16<T> rv; rv.raw = rpre[k];
                 float f[VEC]; rv.unpack(f);
 #pragma unroll
                 for (int i = 0; i < VEC; ++i) v[i] += f[i];
@@ -357,6 +423,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(HaloArgs a) {
         }
     }
     }
+#ifdef MAD_HALO_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    MAD_STAMP_PHASE(3)
+    if (stamp_on) {
+        __syncthreads();
+        for (int i = tid; i < NWAVES * 9 * 8; i += NT) g_stamps[i] = stamp_lds[i];
+    }
+#endif
 }
 
 template <typename T, bool FUSE, int WM, int WN, int TN, bool OUT_NCHW>
@@ -369,7 +443,7 @@ static int launch_halo(const HaloArgs& a, hipStream_t s, const char* what) {
         attr_set = true;
     }
     const int grid = a.B * a.tiles_x * a.tiles_y * a.ntiles_n;
-    hipLaunchKernelGGL((conv3x3_halo_kernel<T, FUSE, WM, WN, TN, OUT_NCHW>), dim3(grid), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((conv3x3_halo_kernel<T, FUSE, WM, WN, TN, OUT_NCHW>), dim3(grid), dim3(64 * WM * WN), lds, s, a);
     return check_launch(what);
 }
 
@@ -385,7 +459,7 @@ extern "C" int mad_conv3x3_fused(const void* x1, int C1, const void* x2, int C2,
     const int CK = dtype == MAD_BF16 ? 32 : 16;
     MAD_REQUIRE(C1 > 0 && C1 % CK == 0 && C2 >= 0 && C2 % CK == 0 && (C2 == 0 || x2),
                 "mad_conv3x3_fused: C1=%d, C2=%d must be multiples of %d", C1, C2, CK);
-    MAD_REQUIRE(Cout > 0 && Cout % 128 == 0, "mad_conv3x3_fused: Cout=%d must be a multiple of 128", Cout);
+    MAD_REQUIRE(Cout > 0 && Cout % 64 == 0, "mad_conv3x3_fused: Cout=%d must be a multiple of 64", Cout);
     MAD_REQUIRE(B > 0 && H >= 16 && W >= 16 && H % 16 == 0 && W % 16 == 0,
                 "mad_conv3x3_fused: H=%d, W=%d must be multiples of 16", H, W);
     MAD_REQUIRE((size_t)B * H * W < (1u << 31), "mad_conv3x3_fused: tensor too large for 32-bit pixel indices");
@@ -397,13 +471,30 @@ extern "C" int mad_conv3x3_fused(const void* x1, int C1, const void* x2, int C2,
     a.C1 = C1; a.C2 = C2; a.B = B; a.H = H; a.W = W; a.Cout = Cout; a.upsample = upsample; a.res_mode = res_mode;
     a.act = act;
     a.Hs = upsample ? H / 2 : H; a.Ws = upsample ? W / 2 : W;
-    a.tiles_x = W / HT; a.tiles_y = H / HT; a.ntiles_n = Cout / 128;
+    a.tiles_x = W / HT; a.tiles_y = H / HT;
     hipStream_t s = (hipStream_t)stream;
     const char* what = "mad_conv3x3_fused";
-    if (dtype == MAD_BF16)
+    // 128 output channels per workgroup unless that leaves the chip (256 CUs, two workgroups each)
+    // under-filled or Cout is an odd multiple of 64: then 64 per workgroup.
+    const int wg128 = B * a.tiles_x * a.tiles_y * (Cout / 128);
+    bool narrow = Cout % 128 != 0 || wg128 < 256;
+    if (const char* f = getenv("MAD_HALO_BN")) narrow = Cout % 128 != 0 || atoi(f) == 64;   // tuning aid
+    a.ntiles_n = Cout / (narrow ? 64 : 128);
+    if (dtype == MAD_BF16) {
+        if (narrow)
+            return coef ? launch_halo<bf16_t, true, 2, 2, 1, false>(a, s, what) : launch_halo<bf16_t, false, 2, 2, 1, false>(a, s, what);
         return coef ? launch_halo<bf16_t, true, 2, 2, 2, false>(a, s, what) : launch_halo<bf16_t, false, 2, 2, 2, false>(a, s, what);
+    }
+    if (narrow)
+        return coef ? launch_halo<float, true, 2, 2, 1, false>(a, s, what) : launch_halo<float, false, 2, 2, 1, false>(a, s, what);
     return coef ? launch_halo<float, true, 2, 2, 2, false>(a, s, what) : launch_halo<float, false, 2, 2, 2, false>(a, s, what);
 }
+
+#ifdef MAD_HALO_STAMPS
+extern "C" int mad_debug_read_stamps(unsigned* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned) * 8 * 9 * 8) == hipSuccess ? 0 : 1;
+}
+#endif
 
 extern "C" int mad_conv_out_fused(const void* x, int Cin, const float* coef, int act, const void* w, const float* bias,
                                   float* y, int dtype, int B, int H, int W, int Cout, void* stream) {

@@ -1,6 +1,7 @@
 // Timestep/class embedding path: sinusoidal embedding and small fp32 linear layers.
 // These are a few MFLOP per evaluation; they stay in fp32 on the vector ALU.
 #include "common.h"
+#include <algorithm>
 
 namespace mad {
 
@@ -14,45 +15,72 @@ __global__ __launch_bounds__(256) void pos_embedding_kernel(const float* t, int 
     emb[(size_t)b * 2 * half + half + i] = sinf(ang);
 }
 
-// One wave per output feature n: the weight row is read once (coalesced), every input row is
-// dotted against it.  ROWS_PER_PASS input rows are processed together to reuse the weight row
-// held in registers.
-template <int ROWS_PER_PASS>
+// y = act_out(x W^T + bias [+ y]).  A block stages up to RT input rows (activated once) in LDS and
+// each wave then produces FT output features for all of them: a weight row is read once per row
+// tile, coalesced, and every staged row is dotted against it from LDS (lane k-strided, conflict-free).
+// The block walks feature groups with a grid stride so the staging cost is shared.
+constexpr int LIN_FT = 2;
+
+template <int RT>
 __global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ x, const float* __restrict__ W,
                                                       const float* __restrict__ bias, float* __restrict__ y,
                                                       int rows, int K, int N, int act_in, int act_out,
                                                       int accumulate) {
-    const int lane = threadIdx.x & 63;
-    const int n = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (n >= N) return;
-    const float* w = W + (size_t)n * K;
-    for (int r0 = 0; r0 < rows; r0 += ROWS_PER_PASS) {
-        float acc[ROWS_PER_PASS];
+    extern __shared__ float xs[];            // RT x K
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
+    for (int r0 = 0; r0 < rows; r0 += RT) {
+        const int nr = min(RT, rows - r0);
+        __syncthreads();
+        for (int i = threadIdx.x; i < RT * K; i += blockDim.x) {
+            const int r = i / K;
+            float v = 0.0f;
+            if (r < nr) {
+                v = x[(size_t)(r0 + r) * K + (i - r * K)];
+                if (act_in) v = silu_f(v);
+            }
+            xs[i] = v;
+        }
+        __syncthreads();
+        for (int g = blockIdx.x * nwave + wave; g * LIN_FT < N; g += gridDim.x * nwave) {
+            const int n0 = g * LIN_FT;
+            float acc[LIN_FT][RT];
 #pragma unroll
-        for (int r = 0; r < ROWS_PER_PASS; ++r) acc[r] = 0.0f;
-        for (int k = lane; k < K; k += 64) {
-            const float wv = w[k];
+            for (int f = 0; f < LIN_FT; ++f)
 #pragma unroll
-            for (int r = 0; r < ROWS_PER_PASS; ++r) {
-                if (r0 + r < rows) {
-                    float xv = x[(size_t)(r0 + r) * K + k];
-                    if (act_in) xv = silu_f(xv);
-                    acc[r] = fmaf(xv, wv, acc[r]);
+                for (int r = 0; r < RT; ++r) acc[f][r] = 0.0f;
+            for (int k = lane; k < K; k += 64) {
+                float wv[LIN_FT];
+#pragma unroll
+                for (int f = 0; f < LIN_FT; ++f) wv[f] = n0 + f < N ? W[(size_t)(n0 + f) * K + k] : 0.0f;
+#pragma unroll
+                for (int r = 0; r < RT; ++r) {
+                    const float xv = xs[r * K + k];
+#pragma unroll
+                    for (int f = 0; f < LIN_FT; ++f) acc[f][r] = fmaf(xv, wv[f], acc[f][r]);
                 }
             }
-        }
 #pragma unroll
-        for (int r = 0; r < ROWS_PER_PASS; ++r) {
-            float v = acc[r];
+            for (int f = 0; f < LIN_FT; ++f)
 #pragma unroll
-            for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-            if (lane == 0 && r0 + r < rows) {
-                if (bias) v += bias[n];
-                float* dst = y + (size_t)(r0 + r) * N + n;
-                if (accumulate) v += *dst;
-                if (act_out) v = silu_f(v);
-                *dst = v;
-            }
+                for (int r = 0; r < RT; ++r) {
+                    float v = acc[f][r];
+#pragma unroll
+                    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+                    acc[f][r] = v;
+                }
+            // every lane holds every sum; results are written by distinct lanes
+#pragma unroll
+            for (int f = 0; f < LIN_FT; ++f)
+#pragma unroll
+                for (int r = 0; r < RT; ++r)
+                    if (lane == ((f * RT + r) & 63) && r < nr && n0 + f < N) {
+                        float v = acc[f][r];
+                        if (bias) v += bias[n0 + f];
+                        float* dst = y + (size_t)(r0 + r) * N + n0 + f;
+                        if (accumulate) v += *dst;
+                        if (act_out) v = silu_f(v);
+                        *dst = v;
+                    }
         }
     }
 }
@@ -76,7 +104,23 @@ extern "C" int mad_linear_f32(const float* x, const float* W, const float* bias,
                               int act_in, int act_out, int accumulate, void* stream) {
     MAD_REQUIRE(x && W && y, "mad_linear_f32: null pointer");
     MAD_REQUIRE(rows > 0 && K > 0 && N > 0, "mad_linear_f32: bad shape rows=%d K=%d N=%d", rows, K, N);
-    hipLaunchKernelGGL(linear_kernel<8>, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, W, bias, y, rows,
-                       K, N, act_in, act_out, accumulate);
+    MAD_REQUIRE(K <= 4096, "mad_linear_f32: K=%d exceeds the staged-row limit 4096", K);
+    const int groups = (N + LIN_FT - 1) / LIN_FT;
+    const int grid = std::min((groups + 3) / 4, 1024);
+    if ((size_t)32 * K * sizeof(float) <= 128 * 1024) {
+        const size_t lds = (size_t)32 * K * sizeof(float);
+        static bool attr_set = false;
+        if (!attr_set) {
+            MAD_REQUIRE(hipFuncSetAttribute((const void*)linear_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            128 * 1024) == hipSuccess,
+                        "mad_linear_f32: cannot raise the dynamic LDS limit");
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(linear_kernel<32>, dim3(grid), dim3(256), lds, (hipStream_t)stream, x, W, bias, y, rows, K,
+                           N, act_in, act_out, accumulate);
+    } else {
+        hipLaunchKernelGGL(linear_kernel<4>, dim3(grid), dim3(256), (size_t)4 * K * sizeof(float),
+                           (hipStream_t)stream, x, W, bias, y, rows, K, N, act_in, act_out, accumulate);
+    }
     return check_launch("mad_linear_f32");
 }

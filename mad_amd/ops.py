@@ -293,7 +293,7 @@ def conv3x3_fused(x1: Tensor, w: Tensor, bias: Optional[Tensor], coef: Optional[
 
 def fused_conv_ok(H: int, W_: int, Cout: int) -> bool:
     """Shapes the halo-tile kernel covers."""
-    return H % 16 == 0 and W_ % 16 == 0 and H >= 16 and W_ >= 16 and Cout % 128 == 0
+    return H % 16 == 0 and W_ % 16 == 0 and H >= 16 and W_ >= 16 and Cout % 64 == 0
 
 
 # ------------------------------------------------------------------------------ GroupNorm

@@ -174,8 +174,12 @@ CONV_CASES = [
 
 @pytest.mark.parametrize("case", CONV_CASES)
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
-def test_conv2d(dev, case, dt):
+@pytest.mark.parametrize("tile", ["auto", "128x128x2", "128x64x2"])
+def test_conv2d(dev, case, dt, tile, monkeypatch):
+    """Every block-tile variant the dispatcher can pick (small inputs alone would only reach 64x64)."""
     from mad_amd import _lib, ops
+    if tile != "auto":
+        monkeypatch.setenv("MAD_IGEMM_TILE", tile)
     B, H, C1, C2, Cout, k, up, res = case
     Hs = H // 2 if up else H
     x1 = _rand((B, C1, Hs, Hs), 1)
@@ -296,13 +300,17 @@ FUSED_CASES = [
     (1, 32, 128, 0, 128, True, True, "up", True),         # nearest x2 of a 16x16 source
     (1, 32, 64, 0, 128, False, False, "down", False),     # plain input, 2x2-mean residual
     (1, 64, 160, 0, 128, True, False, "same", True),      # 5 bf16 chunks / 10 fp32 chunks
+    (1, 32, 96, 0, 192, True, False, "same", True),       # Cout an odd multiple of 64
 ]
 
 
 @pytest.mark.parametrize("case", FUSED_CASES)
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
-def test_conv3x3_fused(dev, case, dt):
+@pytest.mark.parametrize("bn", ["128", "64"])
+def test_conv3x3_fused(dev, case, dt, bn, monkeypatch):
+    """Both workgroup widths (128 and 64 output channels) of the halo-tile kernel."""
     from mad_amd import _lib, ops
+    monkeypatch.setenv("MAD_HALO_BN", bn)
     B, H, C1, C2, Cout, fuse, up, res, want_stats = case
     C = C1 + C2
     Hs = H // 2 if up else H

@@ -23,7 +23,8 @@ def main():
     dev = torch.device("cuda:0")
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
     shapes = [(256, 128, 128), (256, 256, 128), (128, 128, 128), (128, 256, 256), (128, 384, 128), (64, 256, 256),
-              (64, 512, 256), (32, 512, 512), (32, 256, 256), (16, 1024, 512)]
+              (64, 512, 256), (32, 512, 512), (32, 256, 256), (16, 1024, 512), (16, 512, 512)]
+    os.environ["MAD_HALO_BN"] = "128"
     for H, Cin, Cout in shapes:
         x = (torch.randn(B, H, H, Cin, device=dev) * 0.7).to(torch.bfloat16)
         w = (torch.randn(Cout, 3, 3, Cin, device=dev) / math.sqrt(9 * Cin)).to(torch.bfloat16)
@@ -36,6 +37,11 @@ def main():
             t_h0 = timeit(lambda: ops.conv3x3_fused(x, w, bias, coef=None))
             t_h1 = timeit(lambda: ops.conv3x3_fused(x, w, bias, coef=coef, want_stats=True))
             line += f" | halo {t_h0:8.3f} ms {flops / t_h0 / 1e9:8.1f} TF | halo+gn+stats {t_h1:8.3f} ms {flops / t_h1 / 1e9:8.1f} TF"
+            os.environ["MAD_HALO_BN"] = "64"
+            t_n0 = timeit(lambda: ops.conv3x3_fused(x, w, bias, coef=None))
+            t_n1 = timeit(lambda: ops.conv3x3_fused(x, w, bias, coef=coef, want_stats=True))
+            os.environ["MAD_HALO_BN"] = "128"
+            line += f" | narrow {flops / t_n0 / 1e9:7.1f} TF, fused {flops / t_n1 / 1e9:7.1f} TF"
         print(line, flush=True)
 
 
