@@ -12,6 +12,7 @@
 //   conv_in_kernel     first layer (Cin = 3, NCHW fp32 in, NHWC out): direct, bandwidth bound.
 //   conv_out_kernel    last layer (Cout = 3, NHWC in, NCHW fp32 out): direct, bandwidth bound.
 #include "mma.h"
+#include <algorithm>
 #include <cstdlib>
 #include <string>
 
@@ -307,6 +308,88 @@ __global__ __launch_bounds__(256) void conv_in_kernel(const float* __restrict__ 
     }
 }
 
+// First layer on the fp32 matrix pipe (v_mfma_f32_32x32x2_f32, K = 27 padded to 28), same arithmetic
+// type for both activation dtypes.  A workgroup walks 16x8-pixel tiles with a grid stride; the
+// weights ([Cout][29] fp32, odd pitch = conflict-free operand reads) are loaded to LDS once per
+// workgroup.  Per tile: the 3 x 10 x 18 input halo goes to LDS; each wave owns two tile rows (32
+// pixels) x all Cout channels, reads its A operand straight from the halo at the tap's offset, and
+// writes its 32 x Cout result through a wave-private LDS slab as whole 16-byte chunks (NHWC rows of
+// one tile row are contiguous in memory).
+template <typename T, int TN>
+__global__ __launch_bounds__(256) void conv_in_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                            const float* __restrict__ bias, T* __restrict__ y, int B,
+                                                            int H, int W) {
+    constexpr int Cout = TN * 32, WP = 29, VEC = Elem<T>::VEC;
+    constexpr int HALO_N = 3 * 10 * 18;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_m[];
+    float* wl = reinterpret_cast<float*>(smem_m);                  // [Cout][WP]
+    float* halo = wl + Cout * WP;                                  // [3][10][18]
+    T* oslab = reinterpret_cast<T*>(halo + ((HALO_N + 3) & ~3));   // [4 waves][32][Cout]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < Cout * WP; i += 256) {
+        const int n = i / WP, k = i - n * WP;
+        wl[i] = k < 27 ? w[n * 27 + k] : 0.0f;
+    }
+    const int row = lane & 31, kh = lane >> 5;
+    const int pixoff = (wave * 2 + (row >> 4)) * 18 + (row & 15);
+    int koff[14];                            // halo offset of this lane's k = 2s + kh
+#pragma unroll
+    for (int s2 = 0; s2 < 14; ++s2) {
+        const int k = 2 * s2 + kh;
+        const int c = k / 9, r = k - c * 9, ky = r / 3, kx = r - ky * 3;
+        koff[s2] = k < 27 ? c * 180 + ky * 18 + kx : 0;           // k = 27 meets a zero weight
+    }
+    float bcol[TN];
+#pragma unroll
+    for (int jn = 0; jn < TN; ++jn) bcol[jn] = bias[jn * 32 + row];
+    const int tiles_x = W / 16, tiles_y = H / 8;
+    const int ntiles = B * tiles_x * tiles_y;
+    T* const my_slab = oslab + wave * 32 * Cout;
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int b = t / (tiles_x * tiles_y), tt = t - b * tiles_x * tiles_y;
+        const int ty0 = (tt / tiles_x) * 8, tx0 = (tt % tiles_x) * 16;
+        __syncthreads();                     // previous tile's halo reads are done (and the weights are in)
+        for (int i = tid; i < HALO_N; i += 256) {
+            const int c = i / 180, r = i - c * 180, hy = r / 18, hx = r - hy * 18;
+            const int iy = ty0 - 1 + hy, ix = tx0 - 1 + hx;
+            halo[i] = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? x[((size_t)(b * 3 + c) * H + iy) * W + ix] : 0.0f;
+        }
+        __syncthreads();
+        f32x16 acc[TN];
+#pragma unroll
+        for (int jn = 0; jn < TN; ++jn)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[jn][e] = bcol[jn];
+#pragma unroll
+        for (int s2 = 0; s2 < 14; ++s2) {
+            const float av = halo[pixoff + koff[s2]];
+#pragma unroll
+            for (int jn = 0; jn < TN; ++jn) {
+                const float bv = wl[(jn * 32 + row) * WP + 2 * s2 + kh];
+                acc[jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[jn], 0, 0, 0);
+            }
+        }
+        // accumulators -> wave-private slab (pixel-major) -> 16-byte global stores
+#pragma unroll
+        for (int jn = 0; jn < TN; ++jn)
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                my_slab[acc_row(e, lane) * Cout + jn * 32 + row] = Elem<T>::store(acc[jn][e]);
+        __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the slab is private to this wave
+        __builtin_amdgcn_wave_barrier();
+        constexpr int CHUNKS = 32 * Cout / VEC;           // 16-byte chunks of the slab
+#pragma unroll
+        for (int i = 0; i < CHUNKS / 64; ++i) {
+            const int ch = i * 64 + lane;
+            const int p = ch / (Cout / VEC), cv = ch - p * (Cout / VEC);
+            const int oy = ty0 + wave * 2 + (p >> 4), ox = tx0 + (p & 15);
+            const uint4 v = *reinterpret_cast<const uint4*>(my_slab + p * Cout + cv * VEC);
+            *reinterpret_cast<uint4*>(y + (((size_t)b * H + oy) * W + ox) * Cout + cv * VEC) = v;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // --------------------------------------------------------------------------- last layer
 // One thread per output pixel, all (<= 4) output channels; weights (Cout,3,3,Cin) fp32 in LDS are
 // read as wave-wide broadcasts.
@@ -411,13 +494,43 @@ extern "C" int mad_conv_in(const float* x, const float* w, const float* bias, vo
     MAD_REQUIRE(Cout > 0 && Cout % 32 == 0 && Cout <= 256, "mad_conv_in: Cout=%d must be a multiple of 32, <= 256", Cout);
     MAD_REQUIRE(B > 0 && H > 0 && W > 0, "mad_conv_in: bad shape");
     const size_t M = (size_t)B * H * W;
+    hipStream_t st = (hipStream_t)stream;
+    if (H % 8 == 0 && W % 16 == 0 && Cout % 32 == 0 && !getenv("MAD_CONV_IN_DIRECT")) {
+        // matrix-pipe form; tiles are walked with a grid stride so the weights are staged once per workgroup
+        const int ntiles = B * (H / 8) * (W / 16);
+        const dim3 grid((unsigned)std::min(ntiles, 2048));
+        const size_t esz = dtype == MAD_BF16 ? 2 : 4;
+        const size_t lds_m = ((size_t)Cout * 29 + 544) * sizeof(float) + (size_t)4 * 32 * Cout * esz;
+#define MAD_CONV_IN_CASE(TN_)                                                                                     \
+    case TN_:                                                                                                     \
+        if (dtype == MAD_BF16) {                                                                                  \
+            static bool set_b = false;                                                                            \
+            if (!set_b) { hipFuncSetAttribute((const void*)conv_in_mfma_kernel<bf16_t, TN_>,                      \
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set_b = true; } \
+            hipLaunchKernelGGL((conv_in_mfma_kernel<bf16_t, TN_>), grid, dim3(256), lds_m, st, x, w, bias,        \
+                               (bf16_t*)y, B, H, W);                                                              \
+        } else {                                                                                                  \
+            static bool set_f = false;                                                                            \
+            if (!set_f) { hipFuncSetAttribute((const void*)conv_in_mfma_kernel<float, TN_>,                       \
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set_f = true; } \
+            hipLaunchKernelGGL((conv_in_mfma_kernel<float, TN_>), grid, dim3(256), lds_m, st, x, w, bias,         \
+                               (float*)y, B, H, W);                                                               \
+        }                                                                                                         \
+        return check_launch("mad_conv_in");
+        switch (lds_m <= 160 * 1024 ? Cout / 32 : 0) {
+            MAD_CONV_IN_CASE(1) MAD_CONV_IN_CASE(2) MAD_CONV_IN_CASE(3) MAD_CONV_IN_CASE(4)
+            MAD_CONV_IN_CASE(6) MAD_CONV_IN_CASE(8)
+            default: break;                  // other widths take the direct kernel below
+        }
+#undef MAD_CONV_IN_CASE
+    }
     const size_t lds = ((size_t)Cout * Cin * 9 + Cout) * sizeof(float) + (size_t)64 * Cout * (dtype == MAD_BF16 ? 2 : 4);
     dim3 grid((unsigned)((M + 63) / 64));
     if (dtype == MAD_BF16)
-        hipLaunchKernelGGL((conv_in_kernel<bf16_t, 3>), grid, dim3(256), lds, (hipStream_t)stream, x, w, bias,
+        hipLaunchKernelGGL((conv_in_kernel<bf16_t, 3>), grid, dim3(256), lds, st, x, w, bias,
                            (bf16_t*)y, B, H, W, Cout);
     else
-        hipLaunchKernelGGL((conv_in_kernel<float, 3>), grid, dim3(256), lds, (hipStream_t)stream, x, w, bias,
+        hipLaunchKernelGGL((conv_in_kernel<float, 3>), grid, dim3(256), lds, st, x, w, bias,
                            (float*)y, B, H, W, Cout);
     return check_launch("mad_conv_in");
 }

@@ -53,7 +53,7 @@ __device__ unsigned g_stamps[8 * 9 * 8];
 #define MAD_STAMP_PHASE(k)                                                                 \
     if (stamp_on) {                                                                        \
         const unsigned t_ = (unsigned)__builtin_readcyclecounter();                        \
-        if (lane == 0) stamp_lds[(wave * 9 + (k)) * 8 + 5] = t_;                           \
+        if (lane == 0) stamp_lds[(wave * 9 + (k) % 9) * 8 + 5 + (k) / 9] = t_;             \
     }
 #else
 #define MAD_STAMP(pt)
@@ -350,6 +350,7 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / 2) void conv3x3_halo_kernel
             }
         }
         __syncthreads();
+        MAD_STAMP_PHASE(3 + 3 * half)
         if ((wm * ROWS_PER_WAVE) / 128 == half) {
             const int rbase = wm * ROWS_PER_WAVE - half * 128;
 #pragma unroll
@@ -362,6 +363,7 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / 2) void conv3x3_halo_kernel
                             acc[i][jn][e];
         }
         __syncthreads();
+        MAD_STAMP_PHASE(4 + 3 * half)
 #pragma unroll
         for (int k = 0; k < RPT; ++k) {
             const int r = er + k * RPP;
@@ -404,6 +406,7 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / 2) void conv3x3_halo_kernel
                 for (int i = 0; i < VEC; ++i) { ssum[i] += f[i]; ssq[i] = fmaf(f[i], f[i], ssq[i]); }
             }
         }
+        MAD_STAMP_PHASE(5 + 3 * half)
     }
     if (a.stats) {
         // reduce the RPP row-groups per channel in a fixed order
@@ -424,8 +427,9 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / 2) void conv3x3_halo_kernel
     }
     }
 #ifdef MAD_HALO_STAMPS
+    MAD_STAMP_PHASE(2 + 7)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    MAD_STAMP_PHASE(3)
+    MAD_STAMP_PHASE(2 + 8)
     if (stamp_on) {
         __syncthreads();
         for (int i = tid; i < NWAVES * 9 * 8; i += NT) g_stamps[i] = stamp_lds[i];

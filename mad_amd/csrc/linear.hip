@@ -31,14 +31,22 @@ __global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ x
     for (int r0 = 0; r0 < rows; r0 += RT) {
         const int nr = min(RT, rows - r0);
         __syncthreads();
-        for (int i = threadIdx.x; i < RT * K; i += blockDim.x) {
-            const int r = i / K;
-            float v = 0.0f;
-            if (r < nr) {
-                v = x[(size_t)(r0 + r) * K + (i - r * K)];
-                if (act_in) v = silu_f(v);
+        // one row per wave at a time, four rows in flight: independent coalesced loads, no division
+        for (int r = wave; r < RT; r += 4 * nwave) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int rr = r + u * nwave;
+                if (rr < RT) {
+                    for (int k = lane; k < K; k += 64) {
+                        float v = 0.0f;
+                        if (rr < nr) {
+                            v = x[(size_t)(r0 + rr) * K + k];
+                            if (act_in) v = silu_f(v);
+                        }
+                        xs[rr * K + k] = v;
+                    }
+                }
             }
-            xs[i] = v;
         }
         __syncthreads();
         for (int g = blockIdx.x * nwave + wave; g * LIN_FT < N; g += gridDim.x * nwave) {
@@ -106,7 +114,7 @@ extern "C" int mad_linear_f32(const float* x, const float* W, const float* bias,
     MAD_REQUIRE(rows > 0 && K > 0 && N > 0, "mad_linear_f32: bad shape rows=%d K=%d N=%d", rows, K, N);
     MAD_REQUIRE(K <= 4096, "mad_linear_f32: K=%d exceeds the staged-row limit 4096", K);
     const int groups = (N + LIN_FT - 1) / LIN_FT;
-    const int grid = std::min((groups + 3) / 4, 1024);
+    const int grid = std::max(1, std::min((groups + 15) / 16, 512));   // ~4 feature groups per wave
     if ((size_t)32 * K * sizeof(float) <= 128 * 1024) {
         const size_t lds = (size_t)32 * K * sizeof(float);
         static bool attr_set = false;

@@ -211,10 +211,12 @@ def test_conv2d(dev, case, dt, tile, monkeypatch):
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 def test_conv_in_out(dev, dt):
     from mad_amd import ops
-    x = _rand((2, 3, 16, 16), 1)
-    w, b = _rand((64, 3, 3, 3), 2, 0.2), _rand((64,), 3)
-    y = ops.conv_in(x.to(dev), w.to(dev), b.to(dev), dt)
-    assert rel_err(_nchw(y), F.conv2d(x, w, b, padding=1)) < (1e-5 if dt == torch.float32 else 6e-3)
+    # 16x32 and 24x16 take the matrix-pipe kernel (several tiles per image), 12x12 the direct one
+    for shape, cout in [((2, 3, 16, 32), 64), ((3, 3, 24, 16), 128), ((2, 3, 12, 12), 64), ((1, 3, 32, 32), 192)]:
+        x = _rand(shape, 1)
+        w, b = _rand((cout, 3, 3, 3), 2, 0.2), _rand((cout,), 3)
+        y = ops.conv_in(x.to(dev), w.to(dev), b.to(dev), dt)
+        assert rel_err(_nchw(y), F.conv2d(x, w, b, padding=1)) < (1e-5 if dt == torch.float32 else 6e-3), (shape, cout)
     h = _rand((2, 64, 16, 16), 4)
     wo, bo = _rand((3, 64, 3, 3), 5, 0.05), _rand((3,), 6)
     hq = h.to(dt).float()

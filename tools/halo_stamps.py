@@ -30,7 +30,9 @@ for wv in range(4):
         print(f"  tap {tap}: " + "  ".join(f"{n} {v:5d}" for n, v in zip(names, d)) + f"   tap total {nxt}")
 tot = (st[:, 8, 0] - st[:, 0, 0]) & 0xffffffff
 print("8 taps, cycles per wave:", tot, " ideal MFMA issue 8*512 = 4096")
-ph = full[:4, :4, 5]
+ph = np.concatenate([full[:4, :9, 5], full[:4, :2, 6]], axis=1)      # 11 phase stamps per wave
+names = ["prologue", "main loop", "(wait residual+sync)", "h0 acc->LDS+sync", "h0 read/store", "(sync)", "h1 acc->LDS+sync",
+         "h1 read/store", "stats", "store drain"]
 for wv in range(4):
-    d = [(ph[wv, i + 1] - ph[wv, i]) & 0xffffffff for i in range(3)]
-    print(f"wave {wv}: prologue {d[0]}  main loop {d[1]}  epilogue {d[2]}   (chunks: {Cin // 32}; stamped chunk adds ~9*5 stamps)")
+    d = [(ph[wv, i + 1] - ph[wv, i]) & 0xffffffff for i in range(10)]
+    print(f"wave {wv}: " + "  ".join(f"{n} {v}" for n, v in zip(names, d)))

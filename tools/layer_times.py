@@ -7,7 +7,8 @@ from mad_amd import ops
 from mad_amd.config import load_cfg
 from mad_amd.model import build_model
 
-cfg_file = sys.argv[1] if len(sys.argv) > 1 else "configs/model_256_256.yaml"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+cfg_file = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "configs/model_256_256.yaml")
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 32
 dev = torch.device("cuda:0")
 cfg = load_cfg(cfg_file)
