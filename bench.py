@@ -170,6 +170,14 @@ def main():
                         "attention": "attention_kernel", "conv_out": "conv3x3_halo_kernel (last layer)"}
         per_kernel = {k: {"tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12, "ms_per_eval": v["ms"] / max(1, sampled[0]),
                           "launches": v["launches"]} for k, v in mfma.items()}
+        # HBM bytes per launch of the dominant kernel come from separate PMC passes over this command
+        # (tools/pmc_bench.sh); counters cannot be read from inside the timed run
+        traffic, traffic_src = None, None
+        tfile = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_halo_traffic.json")
+        if dom == "conv3x3_halo" and R == 256 and os.path.exists(tfile):
+            with open(tfile) as f:
+                tj = json.load(f)
+            traffic, traffic_src = tj.get("hbm_bytes_per_launch"), "profiles/pmc_halo_traffic.json (rocprofv3 --pmc FETCH_SIZE x2, WRITE_SIZE)"
         line = {
             "metric": "translated images/sec @256x256, fixed-step inversion+denoise (makeup removal)"
                       if R == 256 else f"translated images/sec @{R}x{R}, fixed-step inversion+denoise",
@@ -184,7 +192,8 @@ def main():
                        "gflop_per_image_per_eval": flops_img_eval / 1e9},
             "mfma_util_end_to_end": value * flops_img_eval * evals / 1e12 / (PEAK_BF16_TFLOPS * world),
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_BF16_TFLOPS, "traffic": None,
+                         "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic, "traffic_unit": "bytes/launch",
+                         "traffic_source": traffic_src,
                          "kernel": kernel_names.get(dom, dom),
                          "launches_timed": conv["launches"],
                          "avg_launch_ms": conv["ms"] / conv["launches"] if conv["launches"] else None,

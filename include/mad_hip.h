@@ -138,7 +138,7 @@ int mad_conv2d(const void* x1, int C1, const void* x2, int C2, const void* w, co
                const void* residual, int res_mode, void* y, int dtype, int B, int H, int W,
                int Cout, int ksize, int upsample, void* stream);
 
-/* 3x3 convolution (pad 1, stride 1) for layers with H, W multiples of 16 and Cout a multiple of 128,
+/* 3x3 convolution (pad 1, stride 1) for layers with H, W multiples of 16 and Cout a multiple of 64,
  * with the producer's GroupNorm folded into the operand loader and the consumer's GroupNorm
  * statistics produced by the epilogue:
  *   in(b,y,x,c) = act(x(b,y,x,c)*coef[b,c,0] + coef[b,c,1])   (coef NULL: in = x; zero outside the image)
@@ -153,6 +153,18 @@ int mad_conv3x3_fused(const void* x1, int C1, const void* x2, int C2, const floa
                       const void* w, const float* bias, const void* residual, int res_mode, void* y,
                       float* stats, int dtype, int B, int H, int W, int Cout, int upsample,
                       void* stream);
+
+/* mad_conv3x3_fused plus the residual branch's 1x1 channel projection in the same launch:
+ *   y = conv3x3(in) + bias + sw . s        s = concatenation of sx1 (SC1) and sx2 (SC2), NHWC at (H,W),
+ * sw is (Cout, SC1+SC2) in the activation dtype, `bias` is the sum of the two layers' biases.  The
+ * projection is accumulated as extra K-tiles of the same matrix product (raw input, centre tap).
+ * SC1, SC2 multiples of 32 (bf16) / 16 (fp32); no upsample, no other residual.
+ * Replaces `x = conv1(...)` followed by `x = x + skip(orig)` of a UNetBlock whose channel count
+ * changes (model.py:311-320, 346-353). */
+int mad_conv3x3_fused_skip(const void* x1, int C1, const void* x2, int C2, const float* coef, int act,
+                           const void* w, const float* bias, const void* sx1, int SC1, const void* sx2,
+                           int SC2, const void* sw, void* y, float* stats, int dtype, int B, int H, int W,
+                           int Cout, void* stream);
 
 /* GroupNorm statistics, pass 1: per-(sample, split, channel) sum and sum of squares over the
  * split's pixels of the concatenation of x1 (C1) and x2 (C2).  partial is fp32

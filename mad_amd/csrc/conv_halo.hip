@@ -30,6 +30,9 @@ struct HaloArgs {
     const void* residual; void* y; float* stats;
     int C1, C2, B, H, W, Cout, upsample, res_mode, act;
     int Hs, Ws, tiles_x, tiles_y, ntiles_n;
+    // optional 1x1 projection of a second input added to the result (extra K-tiles, centre tap only)
+    const void* sx1; const void* sx2; const void* sw;
+    int SC1, SC2;
 };
 
 constexpr int HT = 16;                 // output tile edge
@@ -294,6 +297,66 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / 2) void conv3x3_halo_kernel
         }
     }
     dma_wait_all();      // the restaging copies of the last chunk must land before LDS is reused below
+
+    // ---- 1x1 projection of the block input (the residual branch's channel change), accumulated into the
+    // same tiles: K is extended by SC1+SC2 channels read at the centre tap from the raw, un-normalised
+    // input.  The 16x16 pixels of a chunk are staged compactly (pixel p at byte p*64, chunk index XOR
+    // ((p>>2)&3), the weight-tile layout), two buffers, one chunk in flight while one is multiplied.
+    if (a.SC1 > 0) {
+        const int Cs = a.SC1 + a.SC2;
+        const int nskip = Cs / CK;
+        constexpr int SK_ROUNDS = 1024 / NT;
+        auto dma_skip = [&](int sc, int buf) {
+            const int c0 = sc * CK;
+            const T* src; int cs, coff;
+            if (c0 < a.SC1) { src = (const T*)a.sx1; cs = a.SC1; coff = c0; }
+            else { src = (const T*)a.sx2; cs = a.SC2; coff = c0 - a.SC1; }
+#pragma unroll
+            for (int j = 0; j < SK_ROUNDS; ++j) {
+                const int item = tid + NT * j;
+                const int pp = item >> 2;
+                const int lc = (tid & 3) ^ ((pp >> 2) & 3);
+                const size_t pix = ((size_t)b * a.H + ty0 + (pp >> 4)) * a.W + tx0 + (pp & 15);
+                glds16(src + pix * cs + coff + lc * VEC,
+                       __builtin_amdgcn_readfirstlane(halo_base + buf * HALO_BUF + (NT * j + 64 * wave) * 16));
+            }
+#pragma unroll
+            for (int j = 0; j < NW; ++j) {
+                const int blk = (j * NWAVES + wave) % (BN / 16);
+                const int r = blk * 16 + (lane >> 2);
+                const int lchunk = (lane & 3) ^ ((r >> 2) & 3);
+                const T* g = (const T*)a.sw + (size_t)(n0 + r) * Cs + c0 + lchunk * VEC;
+                glds16(g, __builtin_amdgcn_readfirstlane(wt_base + buf * WTILE_BYTES + blk * 16 * HROW));
+            }
+        };
+        int s_off[2];
+        {
+            const int r = wm * (256 / WM) + fr;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) s_off[kk] = r * HROW + (((2 * kk + fh) ^ ((r >> 2) & 3)) << 4);
+        }
+        __syncthreads();                     // every wave has finished reading the last 3x3 tiles
+        dma_skip(0, 0);
+        for (int sc = 0; sc < nskip; ++sc) {
+            dma_wait_all();
+            __syncthreads();
+            if (sc + 1 < nskip) dma_skip(sc + 1, (sc + 1) & 1);
+            const unsigned char* sa = halo0 + (sc & 1) * HALO_BUF;
+            const unsigned char* wt = wt0 + (sc & 1) * WTILE_BYTES;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                uint4 af[TM], bfr[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const uint4*>(sa + s_off[kk] + i * 32 * HROW);
+#pragma unroll
+                for (int jn = 0; jn < TN; ++jn) bfr[jn] = *reinterpret_cast<const uint4*>(wt + b_off[jn][kk]);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int jn = 0; jn < TN; ++jn) mma_chunk<T>(acc[i][jn], af[i], bfr[jn]);
+            }
+        }
+    }
     MAD_STAMP_PHASE(2)
 
     // ---- epilogue, one half tile (8 tile rows = 128 pixels) at a time
@@ -455,14 +518,18 @@ static int launch_halo(const HaloArgs& a, hipStream_t s, const char* what) {
 
 using namespace mad;
 
-extern "C" int mad_conv3x3_fused(const void* x1, int C1, const void* x2, int C2, const float* coef, int act,
-                                 const void* w, const float* bias, const void* residual, int res_mode, void* y,
-                                 float* stats, int dtype, int B, int H, int W, int Cout, int upsample, void* stream) {
+static int conv3x3_fused_impl(const void* x1, int C1, const void* x2, int C2, const float* coef, int act,
+                              const void* w, const float* bias, const void* residual, int res_mode, void* y,
+                              float* stats, int dtype, int B, int H, int W, int Cout, int upsample,
+                              const void* sx1, int SC1, const void* sx2, int SC2, const void* sw, void* stream) {
     MAD_REQUIRE(x1 && w && y, "mad_conv3x3_fused: null pointer");
     MAD_REQUIRE(dtype == MAD_BF16 || dtype == MAD_F32, "mad_conv3x3_fused: bad dtype %d", dtype);
     const int CK = dtype == MAD_BF16 ? 32 : 16;
     MAD_REQUIRE(C1 > 0 && C1 % CK == 0 && C2 >= 0 && C2 % CK == 0 && (C2 == 0 || x2),
                 "mad_conv3x3_fused: C1=%d, C2=%d must be multiples of %d", C1, C2, CK);
+    MAD_REQUIRE(SC1 >= 0 && SC1 % CK == 0 && SC2 >= 0 && SC2 % CK == 0 && (SC1 > 0 || SC2 == 0) &&
+                    (SC1 == 0 || (sx1 && sw)) && (SC2 == 0 || sx2),
+                "mad_conv3x3_fused_skip: SC1=%d, SC2=%d must be multiples of %d with their tensors given", SC1, SC2, CK);
     MAD_REQUIRE(Cout > 0 && Cout % 64 == 0, "mad_conv3x3_fused: Cout=%d must be a multiple of 64", Cout);
     MAD_REQUIRE(B > 0 && H >= 16 && W >= 16 && H % 16 == 0 && W % 16 == 0,
                 "mad_conv3x3_fused: H=%d, W=%d must be multiples of 16", H, W);
@@ -476,6 +543,7 @@ extern "C" int mad_conv3x3_fused(const void* x1, int C1, const void* x2, int C2,
     a.act = act;
     a.Hs = upsample ? H / 2 : H; a.Ws = upsample ? W / 2 : W;
     a.tiles_x = W / HT; a.tiles_y = H / HT;
+    a.sx1 = sx1; a.sx2 = SC2 ? sx2 : sx1; a.sw = sw; a.SC1 = SC1; a.SC2 = SC2;
     hipStream_t s = (hipStream_t)stream;
     const char* what = "mad_conv3x3_fused";
     // 128 output channels per workgroup unless that leaves the chip (256 CUs, two workgroups each)
@@ -492,6 +560,22 @@ extern "C" int mad_conv3x3_fused(const void* x1, int C1, const void* x2, int C2,
     if (narrow)
         return coef ? launch_halo<float, true, 2, 2, 1, false>(a, s, what) : launch_halo<float, false, 2, 2, 1, false>(a, s, what);
     return coef ? launch_halo<float, true, 2, 2, 2, false>(a, s, what) : launch_halo<float, false, 2, 2, 2, false>(a, s, what);
+}
+
+extern "C" int mad_conv3x3_fused(const void* x1, int C1, const void* x2, int C2, const float* coef, int act,
+                                 const void* w, const float* bias, const void* residual, int res_mode, void* y,
+                                 float* stats, int dtype, int B, int H, int W, int Cout, int upsample, void* stream) {
+    return conv3x3_fused_impl(x1, C1, x2, C2, coef, act, w, bias, residual, res_mode, y, stats, dtype, B, H, W, Cout,
+                              upsample, nullptr, 0, nullptr, 0, nullptr, stream);
+}
+
+extern "C" int mad_conv3x3_fused_skip(const void* x1, int C1, const void* x2, int C2, const float* coef, int act,
+                                      const void* w, const float* bias, const void* sx1, int SC1, const void* sx2,
+                                      int SC2, const void* sw, void* y, float* stats, int dtype, int B, int H, int W,
+                                      int Cout, void* stream) {
+    MAD_REQUIRE(SC1 > 0, "mad_conv3x3_fused_skip: SC1=%d, the projected input needs channels", SC1);
+    return conv3x3_fused_impl(x1, C1, x2, C2, coef, act, w, bias, nullptr, MAD_RES_NONE, y, stats, dtype, B, H, W, Cout,
+                              0, sx1, SC1, sx2, SC2, sw, stream);
 }
 
 #ifdef MAD_HALO_STAMPS
@@ -514,6 +598,7 @@ extern "C" int mad_conv_out_fused(const void* x, int Cin, const float* coef, int
     a.x1 = x; a.x2 = x; a.w = w; a.bias = bias; a.coef = coef; a.residual = nullptr; a.y = y; a.stats = nullptr;
     a.C1 = Cin; a.C2 = 0; a.B = B; a.H = H; a.W = W; a.Cout = Cout; a.upsample = 0; a.res_mode = MAD_RES_NONE;
     a.act = act; a.Hs = H; a.Ws = W;
+    a.sx1 = a.sx2 = a.sw = nullptr; a.SC1 = a.SC2 = 0;
     a.tiles_x = W / HT; a.tiles_y = H / HT; a.ntiles_n = 1;
     hipStream_t s = (hipStream_t)stream;
     const char* what = "mad_conv_out_fused";

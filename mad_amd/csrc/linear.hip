@@ -67,28 +67,39 @@ __global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ x
                     for (int f = 0; f < LIN_FT; ++f) acc[f][r] = fmaf(xv, wv[f], acc[f][r]);
                 }
             }
+            // Transposing butterfly: at step `mask` a lane keeps the half of its values whose index has
+            // that bit equal to the lane's and adds the partner's copy of them, so after log2(64) steps
+            // lane l holds the complete sum of value l = f * RT + r (64 values when RT = 32).
+            constexpr int NV = LIN_FT * RT;
+            static_assert(NV <= 64 && (NV & (NV - 1)) == 0, "values per wave must be a power of two <= 64");
+            float vals[NV];
 #pragma unroll
             for (int f = 0; f < LIN_FT; ++f)
 #pragma unroll
-                for (int r = 0; r < RT; ++r) {
-                    float v = acc[f][r];
+                for (int r = 0; r < RT; ++r) vals[f * RT + r] = acc[f][r];
 #pragma unroll
-                    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-                    acc[f][r] = v;
+            for (int mask = 32; mask >= NV; mask >>= 1)          // fewer values than lanes: plain halving first
+#pragma unroll
+                for (int j = 0; j < NV; ++j) vals[j] += __shfl_xor(vals[j], mask);
+#pragma unroll
+            for (int cnt = NV / 2; cnt >= 1; cnt >>= 1) {
+                const bool up = (lane & cnt) != 0;
+#pragma unroll
+                for (int j = 0; j < cnt; ++j) {
+                    const float keep = up ? vals[j + cnt] : vals[j];
+                    const float send = up ? vals[j] : vals[j + cnt];
+                    vals[j] = keep + __shfl_xor(send, cnt);
                 }
-            // every lane holds every sum; results are written by distinct lanes
-#pragma unroll
-            for (int f = 0; f < LIN_FT; ++f)
-#pragma unroll
-                for (int r = 0; r < RT; ++r)
-                    if (lane == ((f * RT + r) & 63) && r < nr && n0 + f < N) {
-                        float v = acc[f][r];
-                        if (bias) v += bias[n0 + f];
-                        float* dst = y + (size_t)(r0 + r) * N + n0 + f;
-                        if (accumulate) v += *dst;
-                        if (act_out) v = silu_f(v);
-                        *dst = v;
-                    }
+            }
+            const int vi = lane & (NV - 1), f = vi / RT, r = vi % RT;
+            if (lane < NV && r < nr && n0 + f < N) {
+                float v = vals[0];
+                if (bias) v += bias[n0 + f];
+                float* dst = y + (size_t)(r0 + r) * N + n0 + f;
+                if (accumulate) v += *dst;
+                if (act_out) v = silu_f(v);
+                *dst = v;
+            }
         }
     }
 }

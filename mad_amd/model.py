@@ -27,6 +27,7 @@ from .init import seeded_state_dict
 from .unet_spec import GN_EPS, BlockSpec, UNetSpec, build_spec, gn_groups, spec_from_cfg
 
 Tensor = torch.Tensor
+LOADER_NORM_MIN_RES = 16      # 3x3 convs above this resolution apply GroupNorm+SiLU in their loader
 
 
 class _Params(nn.Module):
@@ -150,6 +151,8 @@ class DhariwalUNet(nn.Module):
             e["conv1.w"], e["conv1.b"] = cw(f"{n}.conv1.weight"), f32(f"{n}.conv1.bias")
             if b.skip_conv:
                 e["skip.w"], e["skip.b"] = cw(f"{n}.skip.weight"), f32(f"{n}.skip.bias")
+                e["skip.w2d"] = e["skip.w"].reshape(e["skip.w"].shape[0], -1)        # (Cout, Cin) view
+                e["conv1+skip.b"] = (e["conv1.b"] + e["skip.b"]).contiguous()
             if b.attention:
                 # reference channel = head*192 + d*3 + {q,k,v} (model.py:359-363); regroup the rows so a
                 # head's q, k and v are three contiguous 64-channel blocks
@@ -187,7 +190,11 @@ class DhariwalUNet(nn.Module):
         c0 = ops.gn_finalize(self._part(x), hw_in, e["norm0.g"], e["norm0.b"], gn_groups(b.in_channels), GN_EPS,
                              partial2=None if skip is None else self._part(skip))
         ada_v = ada[:, e["ada_off"]:]
-        if b.skip_conv:
+        fused = ops.fused_conv_ok(b.res_out, b.res_out, b.out_channels)
+        proj = None                          # 1x1 projection of the block input folded into conv1's launch
+        if b.skip_conv and fused:
+            res, mode, proj = None, _lib.RES_NONE, (xt, st, e["skip.w2d"])
+        elif b.skip_conv:
             res, mode = ops.conv2d(xt, e["skip.w"], e["skip.b"], x2=st), _lib.RES_SAME
         elif b.up:
             res, mode = xt, _lib.RES_UP
@@ -195,19 +202,32 @@ class DhariwalUNet(nn.Module):
             res, mode = xt, _lib.RES_DOWN
         else:
             res, mode = xt, _lib.RES_SAME
-        if ops.fused_conv_ok(b.res_out, b.res_out, b.out_channels):
+        if fused:
             # halo-tile convs: norm+SiLU of the input applied in the loader, statistics of the output
             # taken in the epilogue
+            # At 16x16 a workgroup covers a whole image and every 64-channel output slice repeats the
+            # loader's norm+SiLU of the same pixels: there a separate (tiny) apply pass is cheaper.
+            in_loader = b.res_out > LOADER_NORM_MIN_RES
             if b.down:
                 h = ops.gn_apply(xt, c0, act=True, x2=st, pool=True)       # 2x2 mean after norm+SiLU
                 h, part = ops.conv3x3_fused(h, e["conv0.w"], e["conv0.b"], coef=None, want_stats=True)
-            else:
+            elif in_loader:
                 h, part = ops.conv3x3_fused(xt, e["conv0.w"], e["conv0.b"], coef=c0, act=True, x2=st,
                                             upsample=b.up, want_stats=True)
+            else:
+                h = ops.gn_apply(xt, c0, act=True, x2=st)                  # before the nearest x2: same values
+                h, part = ops.conv3x3_fused(h, e["conv0.w"], e["conv0.b"], coef=None, upsample=b.up,
+                                            want_stats=True)
             c1 = ops.gn_finalize(part, hw_out, e["norm1.g"], e["norm1.b"], gn_groups(b.out_channels), GN_EPS,
                                  ada=ada_v, ada_stride=ada_total)
-            y, part = ops.conv3x3_fused(h, e["conv1.w"], e["conv1.b"], coef=c1, act=True, residual=res,
-                                        res_mode=mode, want_stats=True)
+            bias1 = e["conv1.b"] if proj is None else e["conv1+skip.b"]
+            if in_loader:
+                y, part = ops.conv3x3_fused(h, e["conv1.w"], bias1, coef=c1, act=True, residual=res,
+                                            res_mode=mode, want_stats=True, skip=proj)
+            else:
+                h = ops.gn_apply(h, c1, act=True)
+                y, part = ops.conv3x3_fused(h, e["conv1.w"], bias1, coef=None, residual=res,
+                                            res_mode=mode, want_stats=True, skip=proj)
             out = _Act(y, part)
         else:
             h = ops.gn_apply(xt, c0, act=True, x2=st, pool=b.down)

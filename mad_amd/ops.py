@@ -261,9 +261,11 @@ def conv2d(x1: Tensor, w: Tensor, bias: Optional[Tensor], x2: Optional[Tensor] =
 
 def conv3x3_fused(x1: Tensor, w: Tensor, bias: Optional[Tensor], coef: Optional[Tensor] = None, act: bool = True,
                   x2: Optional[Tensor] = None, residual: Optional[Tensor] = None, res_mode: int = _lib.RES_NONE,
-                  upsample: bool = False, want_stats: bool = False):
+                  upsample: bool = False, want_stats: bool = False, skip: Optional[tuple] = None):
     """Halo-tile 3x3 conv with the input's GroupNorm(+SiLU) applied in the loader (coef (B,C,2) or None)
-    and, optionally, per-tile statistics of the output (B, tiles, Cout, 2) for the next GroupNorm."""
+    and, optionally, per-tile statistics of the output (B, tiles, Cout, 2) for the next GroupNorm.
+    ``skip=(s1, s2_or_None, sw)`` adds the 1x1 projection ``sw (Cout, SC1+SC2)`` of the raw concatenation
+    [s1, s2] in the same launch (``bias`` must then already hold the sum of both layers' biases)."""
     _dev(x1, x2, w, bias, coef, residual)
     B, Hs, Ws, C1 = x1.shape
     C2 = 0 if x2 is None else x2.shape[3]
@@ -282,6 +284,22 @@ def conv3x3_fused(x1: Tensor, w: Tensor, bias: Optional[Tensor], coef: Optional[
         raise ValueError("res_mode set without a residual tensor")
     y = torch.empty((B, H, W_, Cout), dtype=x1.dtype, device=x1.device)
     stats = torch.empty((B, (H // 16) * (W_ // 16), Cout, 2), dtype=torch.float32, device=x1.device) if want_stats else None
+    if skip is not None:
+        s1, s2, sw = skip
+        _dev(s1, s2, sw)
+        SC1, SC2 = s1.shape[3], (0 if s2 is None else s2.shape[3])
+        if residual is not None or upsample:
+            raise ValueError("conv3x3_fused: the fused projection excludes a residual tensor and upsampling")
+        if (tuple(s1.shape[:3]) != (B, H, W_) or (s2 is not None and tuple(s2.shape[:3]) != (B, H, W_))
+                or tuple(sw.shape) != (Cout, SC1 + SC2) or sw.dtype != x1.dtype or s1.dtype != x1.dtype):
+            raise ValueError("conv3x3_fused: projected input / weight shapes do not fit the output")
+        end = TIMER.bracket("conv3x3_halo", 2.0 * B * H * W_ * Cout * ((C1 + C2) * 9 + SC1 + SC2))
+        check(lib.mad_conv3x3_fused_skip(_ptr(x1), C1, _ptr(x2), C2, _ptr(coef), int(act), _ptr(w), _ptr(bias),
+                                         _ptr(s1), SC1, _ptr(s2), SC2, _ptr(sw), _ptr(y), _ptr(stats),
+                                         _dtype_code(x1), B, H, W_, Cout, _stream()), "mad_conv3x3_fused_skip")
+        if end is not None:
+            end.record()
+        return (y, stats) if want_stats else y
     end = TIMER.bracket("conv3x3_halo", 2.0 * B * H * W_ * Cout * (C1 + C2) * 9)
     check(lib.mad_conv3x3_fused(_ptr(x1), C1, _ptr(x2), C2, _ptr(coef), int(act), _ptr(w), _ptr(bias), _ptr(residual),
                                 res_mode, _ptr(y), _ptr(stats), _dtype_code(x1), B, H, W_, Cout, int(upsample),

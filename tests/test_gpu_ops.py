@@ -357,3 +357,34 @@ def test_conv3x3_fused(dev, case, dt, bn, monkeypatch):
         c1 = ops.gn_finalize(stats, H * H, gamma.to(dev), beta.to(dev), 32, 1e-5)
         c2 = ops.gn_coef(y, gamma.to(dev), beta.to(dev), 32, 1e-5)
         assert rel_err(c1.cpu(), c2.cpu()) < 1e-4
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("bn", ["128", "64"])
+@pytest.mark.parametrize("case", [(2, 32, 64, 64, 32, 128), (1, 16, 128, 96, 0, 192)])
+def test_conv3x3_fused_projection(dev, case, dt, bn, monkeypatch):
+    """conv1 + the residual branch's 1x1 projection of the (two-source) block input in one launch."""
+    from mad_amd import ops
+    monkeypatch.setenv("MAD_HALO_BN", bn)
+    B, H, C, S1, S2, Cout = case
+    h = _rand((B, C, H, H), 1, 1.2)
+    s1, s2 = _rand((B, S1, H, H), 2), (_rand((B, S2, H, H), 3) if S2 else None)
+    w = _rand((Cout, C, 3, 3), 4, 1.0 / math.sqrt(C * 9))
+    sw = _rand((Cout, S1 + S2, 1, 1), 5, 1.0 / math.sqrt(S1 + S2))
+    bias = _rand((Cout,), 6)
+    coef = torch.stack([1 + 0.3 * _rand((B, C), 7), 0.3 * _rand((B, C), 8)], dim=-1)
+    q = (lambda t: t.to(dt).float()) if dt == torch.bfloat16 else (lambda t: t)
+    hin = F.silu(q(h) * coef[:, :, 0, None, None] + coef[:, :, 1, None, None])
+    if dt == torch.bfloat16:
+        hin = q(hin)                                           # the loader rounds the activated value
+    sin = q(s1) if s2 is None else torch.cat([q(s1), q(s2)], 1)
+    want = F.conv2d(hin.double(), q(w).double(), bias.double(), padding=1) + F.conv2d(sin.double(), q(sw).double())
+    y, stats = ops.conv3x3_fused(_nhwc(h, dt, dev), w.permute(0, 2, 3, 1).contiguous().to(dt).to(dev), bias.to(dev),
+                                 coef=coef.to(dev), act=True, want_stats=True,
+                                 skip=(_nhwc(s1, dt, dev), None if s2 is None else _nhwc(s2, dt, dev),
+                                       sw.reshape(Cout, -1).to(dt).to(dev)))
+    assert rel_err(_nchw(y), want) < (2e-5 if dt == torch.float32 else 8e-3)
+    yf = y.float()
+    got = stats.sum(1).cpu()
+    assert rel_err(got[..., 0], yf.sum((1, 2)).cpu()) < 1e-4
+    assert rel_err(got[..., 1], (yf * yf).sum((1, 2)).cpu()) < 1e-4
