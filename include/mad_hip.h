@@ -138,6 +138,14 @@ int mad_conv2d(const void* x1, int C1, const void* x2, int C2, const void* w, co
                const void* residual, int res_mode, void* y, int dtype, int B, int H, int W,
                int Cout, int ksize, int upsample, void* stream);
 
+/* mad_conv2d that also writes the GroupNorm partial sums of its output: stats fp32 (B*H*W/64, Cout, 2),
+ * per-channel sum / sum of squares of every run of 64 consecutive output pixels (H*W a multiple of
+ * 64), i.e. (B, nsplit = H*W/64, Cout, 2) as mad_gn_finalize consumes it.  Replaces the statistics
+ * pass of the GroupNorm that follows the convolution (model.py:182-190). */
+int mad_conv2d_stats(const void* x1, int C1, const void* x2, int C2, const void* w, const float* bias,
+                     const void* residual, int res_mode, void* y, float* stats, int dtype, int B, int H,
+                     int W, int Cout, int ksize, int upsample, void* stream);
+
 /* 3x3 convolution (pad 1, stride 1) for layers with H, W multiples of 16 and Cout a multiple of 64,
  * with the producer's GroupNorm folded into the operand loader and the consumer's GroupNorm
  * statistics produced by the epilogue:

@@ -45,6 +45,8 @@ SIGNATURES = {
                            + [c_void_p]),
     "mad_conv2d": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p]
                    + [c_int] * 7 + [c_void_p]),
+    "mad_conv2d_stats": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
+                                 c_void_p] + [c_int] * 7 + [c_void_p]),
     "mad_conv3x3_fused": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                                   c_int, c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
     "mad_conv3x3_fused_skip": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p,

@@ -24,6 +24,7 @@ struct ConvArgs {
     int M;          // B*H*W
     int Hs, Ws;     // source spatial size (H/2, W/2 when upsample)
     int mtiles, ntiles;
+    float* stats;   // optional (M/64, Cout, 2): per-channel sum / sum of squares of each 64-pixel run of the output
 };
 
 constexpr int ROWB = 128;   // bytes per LDS row = one K-tile of one operand row
@@ -190,6 +191,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
     float bias_v[VEC];
 #pragma unroll
     for (int i = 0; i < VEC; ++i) bias_v[i] = a.bias ? a.bias[n0 + ec + i] : 0.0f;
+    constexpr int HALVES = BM / 64;          // statistics are kept per 64-pixel run
+    float ssum[HALVES][VEC], ssq[HALVES][VEC];
+#pragma unroll
+    for (int h = 0; h < HALVES; ++h)
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) { ssum[h][i] = 0.0f; ssq[h][i] = 0.0f; }
 #pragma unroll
     for (int k = 0; k < NPASS; ++k) {
         const int r = er + k * RPP;
@@ -236,6 +243,34 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
         }
         Vec16<T> o; o.pack(v);
         o.store(y + (size_t)m * a.Cout + n0 + ec);
+        if (a.stats) {
+            float f[VEC]; o.unpack(f);              // statistics of the values as stored
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                ssum[k / (NPASS / HALVES)][i] += f[i];
+                ssq[k / (NPASS / HALVES)][i] = fmaf(f[i], f[i], ssq[k / (NPASS / HALVES)][i]);
+            }
+        }
+    }
+    if (a.stats) {
+        // reduce the RPP row groups per channel in a fixed order, one 64-pixel run at a time
+        float* red = reinterpret_cast<float*>(smem);      // [RPP][BN][2]
+#pragma unroll
+        for (int h = 0; h < HALVES; ++h) {
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                red[(er * BN + ec + i) * 2] = ssum[h][i];
+                red[(er * BN + ec + i) * 2 + 1] = ssq[h][i];
+            }
+            __syncthreads();
+            if (tid < 2 * BN && m0 + h * 64 < a.M) {
+                const int c = tid >> 1, which = tid & 1;
+                float t = 0.0f;
+                for (int g = 0; g < RPP; ++g) t += red[(g * BN + c) * 2 + which];
+                a.stats[((size_t)(m0 / 64 + h) * a.Cout + n0 + c) * 2 + which] = t;
+            }
+        }
     }
 }
 
@@ -463,9 +498,9 @@ template <typename T> static int dispatch_igemm(const ConvArgs& a, hipStream_t s
 
 using namespace mad;
 
-extern "C" int mad_conv2d(const void* x1, int C1, const void* x2, int C2, const void* w, const float* bias,
-                          const void* residual, int res_mode, void* y, int dtype, int B, int H, int W, int Cout,
-                          int ksize, int upsample, void* stream) {
+static int conv2d_impl(const void* x1, int C1, const void* x2, int C2, const void* w, const float* bias,
+                       const void* residual, int res_mode, void* y, float* stats, int dtype, int B, int H, int W,
+                       int Cout, int ksize, int upsample, void* stream) {
     MAD_REQUIRE(x1 && w && y, "mad_conv2d: null pointer");
     MAD_REQUIRE(dtype == MAD_BF16 || dtype == MAD_F32, "mad_conv2d: bad dtype %d", dtype);
     MAD_REQUIRE(ksize == 1 || ksize == 3, "mad_conv2d: ksize must be 1 or 3, got %d", ksize);
@@ -480,10 +515,26 @@ extern "C" int mad_conv2d(const void* x1, int C1, const void* x2, int C2, const 
     ConvArgs a;
     a.x1 = x1; a.x2 = C2 ? x2 : x1; a.w = w; a.bias = bias; a.residual = residual; a.y = y;
     a.C1 = C1; a.C2 = C2; a.B = B; a.H = H; a.W = W; a.Cout = Cout; a.ksize = ksize; a.upsample = upsample;
-    a.res_mode = res_mode; a.M = B * H * W;
+    a.res_mode = res_mode; a.M = B * H * W; a.stats = stats;
+    MAD_REQUIRE(!stats || (H * W) % 64 == 0, "mad_conv2d_stats: H*W=%d must be a multiple of 64", H * W);
     a.Hs = upsample ? H / 2 : H; a.Ws = upsample ? W / 2 : W;
     hipStream_t s = (hipStream_t)stream;
     return dtype == MAD_BF16 ? dispatch_igemm<bf16_t>(a, s) : dispatch_igemm<float>(a, s);
+}
+
+extern "C" int mad_conv2d(const void* x1, int C1, const void* x2, int C2, const void* w, const float* bias,
+                          const void* residual, int res_mode, void* y, int dtype, int B, int H, int W, int Cout,
+                          int ksize, int upsample, void* stream) {
+    return conv2d_impl(x1, C1, x2, C2, w, bias, residual, res_mode, y, nullptr, dtype, B, H, W, Cout, ksize, upsample,
+                       stream);
+}
+
+extern "C" int mad_conv2d_stats(const void* x1, int C1, const void* x2, int C2, const void* w, const float* bias,
+                                const void* residual, int res_mode, void* y, float* stats, int dtype, int B, int H,
+                                int W, int Cout, int ksize, int upsample, void* stream) {
+    MAD_REQUIRE(stats, "mad_conv2d_stats: null statistics pointer");
+    return conv2d_impl(x1, C1, x2, C2, w, bias, residual, res_mode, y, stats, dtype, B, H, W, Cout, ksize, upsample,
+                       stream);
 }
 
 extern "C" int mad_conv_in(const float* x, const float* w, const float* bias, void* y, int dtype, int B, int Cin,

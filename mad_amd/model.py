@@ -230,19 +230,32 @@ class DhariwalUNet(nn.Module):
                                             res_mode=mode, want_stats=True, skip=proj)
             out = _Act(y, part)
         else:
+            stats_ok = hw_out % 64 == 0       # the implicit GEMM's epilogue can then take the statistics
             h = ops.gn_apply(xt, c0, act=True, x2=st, pool=b.down)
-            h = ops.conv2d(h, e["conv0.w"], e["conv0.b"], upsample=b.up)
-            c1 = ops.gn_coef(h, e["norm1.g"], e["norm1.b"], gn_groups(b.out_channels), GN_EPS,
-                             ada=ada_v, ada_stride=ada_total)
+            if stats_ok:
+                h, part = ops.conv2d(h, e["conv0.w"], e["conv0.b"], upsample=b.up, want_stats=True)
+                c1 = ops.gn_finalize(part, hw_out, e["norm1.g"], e["norm1.b"], gn_groups(b.out_channels), GN_EPS,
+                                     ada=ada_v, ada_stride=ada_total)
+            else:
+                h = ops.conv2d(h, e["conv0.w"], e["conv0.b"], upsample=b.up)
+                c1 = ops.gn_coef(h, e["norm1.g"], e["norm1.b"], gn_groups(b.out_channels), GN_EPS,
+                                 ada=ada_v, ada_stride=ada_total)
             h = ops.gn_apply(h, c1, act=True)
-            out = _Act(ops.conv2d(h, e["conv1.w"], e["conv1.b"], residual=res, res_mode=mode))
+            if stats_ok:
+                out = _Act(*ops.conv2d(h, e["conv1.w"], e["conv1.b"], residual=res, res_mode=mode, want_stats=True))
+            else:
+                out = _Act(ops.conv2d(h, e["conv1.w"], e["conv1.b"], residual=res, res_mode=mode))
         if b.attention:
             c2 = ops.gn_finalize(self._part(out), hw_out, e["norm2.g"], e["norm2.b"], gn_groups(b.out_channels),
                                  GN_EPS)
             h = ops.gn_apply(out.t, c2, act=False)
             qkv = ops.conv2d(h, e["qkv.w"], e["qkv.b"])
             a = ops.attention(qkv, b.num_heads)
-            out = _Act(ops.conv2d(a, e["proj.w"], e["proj.b"], residual=out.t, res_mode=_lib.RES_SAME))
+            if hw_out % 64 == 0:
+                out = _Act(*ops.conv2d(a, e["proj.w"], e["proj.b"], residual=out.t, res_mode=_lib.RES_SAME,
+                                       want_stats=True))
+            else:
+                out = _Act(ops.conv2d(a, e["proj.w"], e["proj.b"], residual=out.t, res_mode=_lib.RES_SAME))
         return out
 
     @torch.no_grad()

@@ -230,8 +230,11 @@ def conv_out_fused(x: Tensor, w32: Tensor, bias: Tensor, cout: int, coef: Option
 
 
 def conv2d(x1: Tensor, w: Tensor, bias: Optional[Tensor], x2: Optional[Tensor] = None,
-           residual: Optional[Tensor] = None, res_mode: int = _lib.RES_NONE, upsample: bool = False) -> Tensor:
-    """Implicit-GEMM conv; x NHWC, w (Cout,k,k,C1+C2) in the activation dtype, bias fp32."""
+           residual: Optional[Tensor] = None, res_mode: int = _lib.RES_NONE, upsample: bool = False,
+           want_stats: bool = False):
+    """Implicit-GEMM conv; x NHWC, w (Cout,k,k,C1+C2) in the activation dtype, bias fp32.  With
+    ``want_stats`` (H*W a multiple of 64) also returns the output's GroupNorm partial sums
+    (B, H*W/64, Cout, 2) written by the epilogue."""
     _dev(x1, x2, w, bias, residual)
     B, Hs, Ws, C1 = x1.shape
     C2 = 0 if x2 is None else x2.shape[3]
@@ -252,11 +255,20 @@ def conv2d(x1: Tensor, w: Tensor, bias: Optional[Tensor], x2: Optional[Tensor] =
         raise ValueError("res_mode set without a residual tensor")
     y = torch.empty((B, H, W_, Cout), dtype=x1.dtype, device=x1.device)
     end = TIMER.bracket("conv_igemm", 2.0 * B * H * W_ * Cout * (C1 + C2) * k * k)
-    check(lib.mad_conv2d(_ptr(x1), C1, _ptr(x2), C2, _ptr(w), _ptr(bias), _ptr(residual), res_mode, _ptr(y),
-                         _dtype_code(x1), B, H, W_, Cout, k, int(upsample), _stream()), "mad_conv2d")
+    if want_stats:
+        if (H * W_) % 64:
+            raise ValueError(f"conv2d statistics need H*W ({H * W_}) to be a multiple of 64")
+        stats = torch.empty((B, H * W_ // 64, Cout, 2), dtype=torch.float32, device=x1.device)
+        check(lib.mad_conv2d_stats(_ptr(x1), C1, _ptr(x2), C2, _ptr(w), _ptr(bias), _ptr(residual), res_mode, _ptr(y),
+                                   _ptr(stats), _dtype_code(x1), B, H, W_, Cout, k, int(upsample), _stream()),
+              "mad_conv2d_stats")
+    else:
+        stats = None
+        check(lib.mad_conv2d(_ptr(x1), C1, _ptr(x2), C2, _ptr(w), _ptr(bias), _ptr(residual), res_mode, _ptr(y),
+                             _dtype_code(x1), B, H, W_, Cout, k, int(upsample), _stream()), "mad_conv2d")
     if end is not None:
         end.record()
-    return y
+    return (y, stats) if want_stats else y
 
 
 def conv3x3_fused(x1: Tensor, w: Tensor, bias: Optional[Tensor], coef: Optional[Tensor] = None, act: bool = True,

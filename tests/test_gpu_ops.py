@@ -206,6 +206,15 @@ def test_conv2d(dev, case, dt, tile, monkeypatch):
     assert tuple(y.shape) == (B, H, H, Cout)
     tol = 2e-5 if dt == torch.float32 else 6e-3       # bf16: inputs are pre-rounded, only the output rounds
     assert rel_err(_nchw(y), want) < tol
+    # the same launch with the epilogue's GroupNorm partial sums: identical output, sums of what was stored
+    y2, stats = ops.conv2d(_nhwc(x1, dt, dev), w.permute(0, 2, 3, 1).contiguous().to(dt).to(dev), b.to(dev),
+                           x2=None if x2 is None else _nhwc(x2, dt, dev),
+                           residual=None if r is None else _nhwc(r, dt, dev), res_mode=mode, upsample=up,
+                           want_stats=True)
+    assert torch.equal(y2, y) and tuple(stats.shape) == (B, H * H // 64, Cout, 2)
+    runs = y.float().reshape(B, H * H // 64, 64, Cout)
+    assert rel_err(stats[..., 0].cpu(), runs.sum(2).cpu()) < 1e-4
+    assert rel_err(stats[..., 1].cpu(), (runs * runs).sum(2).cpu()) < 1e-4
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
