@@ -64,7 +64,7 @@ __device__ unsigned g_stamps[8 * 9 * 8];
 #endif
 
 template <int BN> constexpr int halo_lds_bytes() {
-    constexpr int stage = 2 * HALO_BUF + NWBUF * BN * HROW + 2 * CTAB_BYTES;
+    constexpr int stage = 2 * HALO_BUF + NWBUF * BN * HROW + 2 * CTAB_BYTES + 1024;   // + one sink KiB
     constexpr int epi = 128 * (BN + 4) * 4;
 #ifdef MAD_HALO_STAMPS
     return (stage > epi ? stage : epi) + 4096;
@@ -74,7 +74,7 @@ template <int BN> constexpr int halo_lds_bytes() {
 }
 
 // OUT_NCHW: write the first a.Cout (<= BN) channels as NCHW fp32 with bias (last layer).
-template <typename T, bool FUSE, int WM, int WN, int TN, bool OUT_NCHW>
+template <typename T, bool FUSE, int WM, int WN, int TN, bool OUT_NCHW, bool SKIP>
 __global__ __launch_bounds__(64 * WM * WN, WM * WN / 2) void conv3x3_halo_kernel(HaloArgs a) {
     constexpr int NWAVES = WM * WN, NT = 64 * NWAVES;
     static_assert(NWAVES == 4 || NWAVES == 8, "4 or 8 waves");
@@ -91,6 +91,7 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / 2) void conv3x3_halo_kernel
     unsigned char* const halo0 = smem;
     unsigned char* const wt0 = smem + 2 * HALO_BUF;
     unsigned char* const ctab0 = wt0 + NWBUF * WTILE_BYTES;
+    unsigned char* const sink0 = ctab0 + 2 * CTAB_BYTES;     // target of copies that only keep op counts equal
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -121,15 +122,15 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / 2) void conv3x3_halo_kernel
 
     // ---- halo staging assignment.  Item = tid + NT*j sits at LDS offset item*16 (lane-linear, as LDS-DMA
     // requires): pixel p = item>>2, physical chunk tid&3, which holds logical chunk (tid&3) ^ ((hx>>1)&3).
-    // In the last round only the first wave(s) have real items; the others repeat their previous copy so
-    // that every wave issues the same number of memory operations (the counted waits below rely on it).
+    // In the last round only the first wave(s) have real items; the others copy the zero page into a sink
+    // area that nobody reads, so that every wave issues the same number of memory operations (the counted
+    // waits below rely on it) and no copy can land on an item that was already transformed in place.
     const bool last_round_real = NT * (HALO_ROUNDS - 1) + 64 * wave < HALO_BUF / 16;
     int src_pix[HALO_ROUNDS];        // source pixel index (b*Hs + sy)*Ws + sx, or -1: padding / no item
     unsigned lchunks = 0;            // 2 bits per round: logical chunk of this thread's item
 #pragma unroll
     for (int j = 0; j < HALO_ROUNDS; ++j) {
-        const int jj = (j == HALO_ROUNDS - 1 && !last_round_real) ? j - 1 : j;
-        const int item = tid + NT * jj;
+        const int item = tid + NT * j;
         const int p = item >> 2;
         const int hy = p / HS, hx = p - hy * HS;
         const int iy = ty0 - 1 + hy, ix = tx0 - 1 + hx;
@@ -139,6 +140,7 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / 2) void conv3x3_halo_kernel
         lchunks |= (unsigned)((tid & 3) ^ ((hx >> 1) & 3)) << (2 * j);
     }
     const unsigned halo_base = lds_addr(halo0);
+    const unsigned sink_base = lds_addr(sink0);
     auto dma_item = [&](int cc, int j, int buf) {
         const int c0 = cc * CK;
         const T* src; int cs, coff;
@@ -147,8 +149,9 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / 2) void conv3x3_halo_kernel
         const int lc = (lchunks >> (2 * j)) & 3;
         const T* p = src + (size_t)max(src_pix[j], 0) * cs + coff + lc * VEC;
         const void* g = src_pix[j] >= 0 ? (const void*)p : (const void*)g_zero_page;
-        const int jj = (j == HALO_ROUNDS - 1 && !last_round_real) ? j - 1 : j;
-        glds16(g, __builtin_amdgcn_readfirstlane(halo_base + buf * HALO_BUF + (NT * jj + 64 * wave) * 16));
+        const bool sink = j == HALO_ROUNDS - 1 && !last_round_real;     // wave-uniform
+        const unsigned dst = sink ? sink_base : halo_base + buf * HALO_BUF + (NT * j + 64 * wave) * 16;
+        glds16(sink ? (const void*)g_zero_page : g, __builtin_amdgcn_readfirstlane(dst));
     };
     // GroupNorm coefficient table of one chunk: CK channels x (a, d) fp32, same copy from every wave
     const unsigned ctab_base = lds_addr(ctab0);
@@ -225,10 +228,29 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / 2) void conv3x3_halo_kernel
     for (int j = 0; j < HALO_ROUNDS; ++j) dma_item(0, j, 0);
     stage_w(0, 0, 0);
     stage_w(0, 1, 1);
-    dma_wait_all();
-    if (FUSE) __syncthreads();                     // the coefficient table is written by lanes of wave 0..3 alike
+    if (FUSE) {
+        // Copies retire in issue order: item j is transformed as soon as it (and the table, which every
+        // wave copies for itself) has landed, while the later items and the weight tiles are still in flight.
+        static_assert(HALO_ROUNDS - 1 + 2 * NW < 64, "vmcnt range");
 #pragma unroll
-    for (int j = 0; j < HALO_ROUNDS; ++j) xform_item(j, 0);
+        for (int j = 0; j < HALO_ROUNDS; ++j) {
+            switch (HALO_ROUNDS - 1 - j + 2 * NW) {
+                case 0: dma_wait_upto<0>(); break;
+                case 1: dma_wait_upto<1>(); break;
+                case 2: dma_wait_upto<2>(); break;
+                case 3: dma_wait_upto<3>(); break;
+                case 4: dma_wait_upto<4>(); break;
+                case 5: dma_wait_upto<5>(); break;
+                case 6: dma_wait_upto<6>(); break;
+                case 7: dma_wait_upto<7>(); break;
+                case 8: dma_wait_upto<8>(); break;
+                case 9: dma_wait_upto<9>(); break;
+                default: dma_wait_all(); break;
+            }
+            xform_item(j, 0);
+        }
+    }
+    dma_wait_all();
 
     // Operations a wave issues at tap t, in order: NW weight copies (K-tile t+2), the coefficient copy
     // (t == 0, FUSE), one halo item (t < 6).  Weight tile t was issued first at tap t-2, so at the top of
@@ -302,7 +324,7 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / 2) void conv3x3_halo_kernel
     // same tiles: K is extended by SC1+SC2 channels read at the centre tap from the raw, un-normalised
     // input.  The 16x16 pixels of a chunk are staged compactly (pixel p at byte p*64, chunk index XOR
     // ((p>>2)&3), the weight-tile layout), two buffers, one chunk in flight while one is multiplied.
-    if (a.SC1 > 0) {
+    if constexpr (SKIP) {
         const int Cs = a.SC1 + a.SC2;
         const int nskip = Cs / CK;
         constexpr int SK_ROUNDS = 1024 / NT;
@@ -500,17 +522,17 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / 2) void conv3x3_halo_kernel
 #endif
 }
 
-template <typename T, bool FUSE, int WM, int WN, int TN, bool OUT_NCHW>
+template <typename T, bool FUSE, int WM, int WN, int TN, bool OUT_NCHW, bool SKIP = false>
 static int launch_halo(const HaloArgs& a, hipStream_t s, const char* what) {
     constexpr int lds = halo_lds_bytes<WN * TN * 32>();
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<T, FUSE, WM, WN, TN, OUT_NCHW>),
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<T, FUSE, WM, WN, TN, OUT_NCHW, SKIP>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
     const int grid = a.B * a.tiles_x * a.tiles_y * a.ntiles_n;
-    hipLaunchKernelGGL((conv3x3_halo_kernel<T, FUSE, WM, WN, TN, OUT_NCHW>), dim3(grid), dim3(64 * WM * WN), lds, s, a);
+    hipLaunchKernelGGL((conv3x3_halo_kernel<T, FUSE, WM, WN, TN, OUT_NCHW, SKIP>), dim3(grid), dim3(64 * WM * WN), lds, s, a);
     return check_launch(what);
 }
 
@@ -552,14 +574,21 @@ static int conv3x3_fused_impl(const void* x1, int C1, const void* x2, int C2, co
     bool narrow = Cout % 128 != 0 || wg128 < 256;
     if (const char* f = getenv("MAD_HALO_BN")) narrow = Cout % 128 != 0 || atoi(f) == 64;   // tuning aid
     a.ntiles_n = Cout / (narrow ? 64 : 128);
+#define MAD_HALO_DISPATCH(T_, TN_)                                                                    \
+    do {                                                                                              \
+        if (SC1 > 0)                                                                                  \
+            return coef ? launch_halo<T_, true, 2, 2, TN_, false, true>(a, s, what)                   \
+                        : launch_halo<T_, false, 2, 2, TN_, false, true>(a, s, what);                 \
+        return coef ? launch_halo<T_, true, 2, 2, TN_, false>(a, s, what)                             \
+                    : launch_halo<T_, false, 2, 2, TN_, false>(a, s, what);                           \
+    } while (0)
     if (dtype == MAD_BF16) {
-        if (narrow)
-            return coef ? launch_halo<bf16_t, true, 2, 2, 1, false>(a, s, what) : launch_halo<bf16_t, false, 2, 2, 1, false>(a, s, what);
-        return coef ? launch_halo<bf16_t, true, 2, 2, 2, false>(a, s, what) : launch_halo<bf16_t, false, 2, 2, 2, false>(a, s, what);
+        if (narrow) MAD_HALO_DISPATCH(bf16_t, 1);
+        MAD_HALO_DISPATCH(bf16_t, 2);
     }
-    if (narrow)
-        return coef ? launch_halo<float, true, 2, 2, 1, false>(a, s, what) : launch_halo<float, false, 2, 2, 1, false>(a, s, what);
-    return coef ? launch_halo<float, true, 2, 2, 2, false>(a, s, what) : launch_halo<float, false, 2, 2, 2, false>(a, s, what);
+    if (narrow) MAD_HALO_DISPATCH(float, 1);
+    MAD_HALO_DISPATCH(float, 2);
+#undef MAD_HALO_DISPATCH
 }
 
 extern "C" int mad_conv3x3_fused(const void* x1, int C1, const void* x2, int C2, const float* coef, int act,

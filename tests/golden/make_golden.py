@@ -368,5 +368,105 @@ def main():
     np.savez_compressed(os.path.join(HERE, "trajectory.npz"), **traj)
 
 
+def refine_and_inversion_goldens():
+    """trajectory_refine.npz: the refine loop of ``generate`` (translation.py:842-868) and the
+    DDIM-inversion start (``inverse_diffusion`` + ``noise_initialize``, translation.py:282-301, 666-672,
+    778-789) run by the reference's own loops on a tiny denoiser, every random draw recorded."""
+    install_placeholders()
+    sys.path.insert(0, REF)
+    import modeling.model as ref_model
+    import modeling.scheduler as ref_sched
+    import modeling.translation as ref_trans
+    from mad_amd.config import load_cfg
+    from mad_amd.unet_spec import spec_from_cfg
+
+    torch.set_grad_enabled(False)
+    cfg = load_cfg(os.path.join(REPO, "configs", "model_tiny.yaml"))
+    spec = spec_from_cfg(cfg)
+    net = Adapter(build_ref_unet(ref_model, spec, seed=1))
+    out = {}
+
+    def make_td(cls, sample_steps, refine_iterations, refine_steps):
+        td = ref_trans.TranslationDiffusion.__new__(ref_trans.TranslationDiffusion)
+        td.device, td.num_classes, td.sample_steps = "cpu", 2, sample_steps
+        td.refine_iterations, td.refine_steps, td.eta, td.null_text = refine_iterations, refine_steps, 0.01, None
+        td.scheduler = cls(num_train_timesteps=1000, prediction_type="epsilon", beta_schedule="linear",
+                           beta_start=1e-4, beta_end=0.02)
+        return td
+
+    def recorded(fn):
+        draws = []
+        real_randn, real_randn_like = torch.randn, torch.randn_like
+
+        def rec_randn(*a, **k):
+            z = real_randn(*a, **k)
+            draws.append(z.clone())
+            return z
+
+        def rec_randn_like(x, **k):
+            z = real_randn_like(x, **k)
+            draws.append(z.clone())
+            return z
+
+        torch.randn, torch.randn_like = rec_randn, rec_randn_like
+        try:
+            res = fn()
+        finally:
+            torch.randn, torch.randn_like = real_randn, real_randn_like
+        return res, draws
+
+    image = (seeded_inputs((2, 3, 16, 16), 43) * 0.4).clamp(-0.9, 0.9)
+    mask = (seeded_inputs((1, 16, 16), 10) > 0.3).float()
+    out["image"], out["mask"] = image.numpy(), mask.numpy()
+
+    # ---- refine loop, DDPM table, with and without a keep-mask
+    td = make_td(ref_sched.CustomDDPMScheduler, 1000, refine_iterations=2, refine_steps=3)
+    src, tgt = td.process_label(0, 2), td.process_label(1, 2)
+    torch.manual_seed(4321)
+    start = 10
+    eps_list, d_enc = recorded(lambda: td.encode(image, src, net, start_from_step=start))
+    out["refine/start"] = np.int64(start)
+    out["refine/eps_list"] = eps_list.numpy()
+    for tag, m in (("nomask", None), ("mask", mask)):
+        res, d = recorded(lambda: td.generate(net, eps_list=eps_list, class_label=tgt, source_image=image.clone(),
+                                              source_mask=m, start_from_step=start))
+        out[f"refine/{tag}/draws"] = torch.stack(d).numpy()
+        out[f"refine/{tag}/out"] = res.numpy()
+        print(f"refine {tag}: {len(d)} draws, out range {float(res.min()):.3f}..{float(res.max()):.3f}")
+
+    # ---- DDIM inversion as the starting latent; the reference asks for device="cuda" there
+    # (translation.py:290), which this CPU-only container maps to the CPU
+    td = make_td(ref_sched.CustomDDIMScheduler, 50, 0, 0)
+    orig_set_inv = td.scheduler.set_inverse_timesteps
+    td.scheduler.set_inverse_timesteps = lambda n, device=None: orig_set_inv(n, device="cpu")
+    inverse_step = 20
+    torch.manual_seed(999)
+    latent, d0 = recorded(lambda: td.inverse_diffusion(net, image, tgt, inverse_step=inverse_step))
+    assert not d0
+    out["inversion/inverse_step"] = np.int64(inverse_step)
+    out["inversion/latent"] = latent.numpy()
+    # (a) latent alone as the start of a full 50-step generation with fresh noise
+    res, d = recorded(lambda: td.generate(net, eps_list=None, class_label=tgt, source_image=image.clone(),
+                                          source_mask=mask, noise_initialize=latent, start_from_step=-1))
+    out["inversion/latent_only/draws"] = torch.stack(d).numpy() if d else np.zeros((0,), np.float32)
+    out["inversion/latent_only/out"] = res.numpy()
+    # (b) use_eps and use_inversion together (domain_translation's combination), start_from_step = 30
+    start = 30
+    eps_list, d_enc = recorded(lambda: td.encode(image, src, net, start_from_step=start))
+    res, d = recorded(lambda: td.generate(net, eps_list=eps_list, class_label=tgt, source_image=image.clone(),
+                                          source_mask=mask, noise_initialize=latent, start_from_step=start))
+    out["inversion/both/start"] = np.int64(start)
+    out["inversion/both/eps_list"] = eps_list.numpy()
+    out["inversion/both/draws"] = torch.stack(d).numpy()
+    out["inversion/both/out"] = res.numpy()
+    print(f"inversion: latent |x| {float(latent.abs().max()):.3f}, draws latent_only "
+          f"{len(out['inversion/latent_only/draws'])}, both {len(d)}")
+    np.savez_compressed(os.path.join(HERE, "trajectory_refine.npz"), **out)
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "refine":
+        refine_and_inversion_goldens()
+    else:
+        main()
+        refine_and_inversion_goldens()

@@ -169,3 +169,48 @@ def test_transfer_loop_runs_with_component_masks(dev):
     assert float(out.min()) >= 0.0 and float(out.max()) <= 1.0 and torch.isfinite(out).all()
     with pytest.raises(NotImplementedError):
         td.image_translation(m, m, src, src, 0, 1)
+
+
+def test_refine_loop_matches_reference(dev):
+    """generate() with the refine loop on (REFINE_ITERATIONS=2, REFINE_STEPS=3), reference draws replayed."""
+    from mad_amd.translation import TranslationDiffusion
+    g = load_golden("trajectory_refine.npz")
+    cfg, m = _model("model_tiny.yaml", "fp32", 1, dev)
+    cfg.EVAL.SCHEDULER, cfg.EVAL.SAMPLE_STEPS, cfg.EVAL.ETA = "ddpm", 1000, 0.01
+    cfg.EVAL.REFINE_ITERATIONS, cfg.EVAL.REFINE_STEPS = 2, 3
+    image, start = torch.from_numpy(g["image"]).to(dev), int(g["refine/start"])
+    eps = torch.from_numpy(g["refine/eps_list"]).to(dev)
+    for tag, mask in (("nomask", None), ("mask", torch.from_numpy(g["mask"]).to(dev))):
+        td = TranslationDiffusion(cfg, dev)
+        draws = iter(torch.from_numpy(g[f"refine/{tag}/draws"]))
+        td.noise_source = lambda shape: next(draws)
+        out = td.generate(m, eps_list=eps, class_label=td.process_label(1, 2), source_image=image.clone(),
+                          source_mask=mask, start_from_step=start)
+        assert next(draws, None) is None
+        assert float((out - torch.from_numpy(g[f"refine/{tag}/out"])).abs().max()) < 5e-4, tag
+
+
+def test_inversion_start_matches_reference(dev):
+    """inverse_diffusion and generate(noise_initialize=...) alone and together with eps_list."""
+    from mad_amd.translation import TranslationDiffusion
+    g = load_golden("trajectory_refine.npz")
+    cfg, m = _model("model_tiny.yaml", "fp32", 1, dev)
+    cfg.EVAL.SCHEDULER, cfg.EVAL.SAMPLE_STEPS, cfg.EVAL.ETA = "ddim", 50, 0.01
+    image, mask = torch.from_numpy(g["image"]).to(dev), torch.from_numpy(g["mask"]).to(dev)
+    td = TranslationDiffusion(cfg, dev)
+    tgt = td.process_label(1, 2)
+    latent = td.inverse_diffusion(m, image, tgt, inverse_step=int(g["inversion/inverse_step"]))
+    ref_latent = torch.from_numpy(g["inversion/latent"])
+    assert rel_err(latent.cpu(), ref_latent) < 1e-4
+    draws = iter(torch.from_numpy(g["inversion/latent_only/draws"]))
+    td.noise_source = lambda shape: next(draws)
+    out = td.generate(m, eps_list=None, class_label=tgt, source_image=image.clone(), source_mask=mask,
+                      noise_initialize=ref_latent.to(dev), start_from_step=-1)
+    assert float((out - torch.from_numpy(g["inversion/latent_only/out"])).abs().max()) < 5e-4
+    td = TranslationDiffusion(cfg, dev)
+    draws2 = iter(torch.from_numpy(g["inversion/both/draws"]))
+    td.noise_source = lambda shape: next(draws2)
+    out = td.generate(m, eps_list=torch.from_numpy(g["inversion/both/eps_list"]).to(dev), class_label=tgt,
+                      source_image=image.clone(), source_mask=mask, noise_initialize=ref_latent.to(dev),
+                      start_from_step=int(g["inversion/both/start"]))
+    assert float((out - torch.from_numpy(g["inversion/both/out"])).abs().max()) < 5e-4

@@ -153,3 +153,46 @@ def test_trajectory_matches_reference(kind):
     out = tr.generate(model, eps_list=ref_eps, class_label=tgt, source_image=image,
                       source_mask=torch.from_numpy(g[f"{kind}/mask"]), start_from_step=start)
     assert float((out - torch.from_numpy(g[f"{kind}/out_target_masked"])).abs().max()) < tol
+
+
+def test_refine_loop_matches_reference():
+    """generate() with REFINE_ITERATIONS=2, REFINE_STEPS=3 (translation.py:842-868), draws replayed."""
+    g = load_golden("trajectory_refine.npz")
+    spec, sd, kw = _oracle_unet("model_tiny.yaml", 1)
+    model = lambda x, t, labels: unet_forward(sd, x, t, labels, **kw)
+    image, start = torch.from_numpy(g["image"]), int(g["refine/start"])
+    eps = torch.from_numpy(g["refine/eps_list"])
+    for tag, mask in (("nomask", None), ("mask", torch.from_numpy(g["mask"]))):
+        draws = iter(torch.from_numpy(g[f"refine/{tag}/draws"]))
+        tr = RefTranslation(RefScheduler("ddpm"), 2, sample_steps=1000, eta=0.01, refine_steps=3,
+                            refine_iterations=2, randn=lambda shape: next(draws))
+        out = tr.generate(model, eps_list=eps, class_label=tr.process_label(1, 2), source_image=image,
+                          source_mask=mask, start_from_step=start)
+        assert next(draws, None) is None                       # every recorded draw was consumed
+        assert float((out - torch.from_numpy(g[f"refine/{tag}/out"])).abs().max()) < 2e-4, tag
+
+
+def test_inversion_start_matches_reference():
+    """inverse_diffusion (translation.py:282-301) and generate(noise_initialize=...) alone and together
+    with eps_list (the use_eps + use_inversion combination of domain_translation, :666-672, 778-789)."""
+    g = load_golden("trajectory_refine.npz")
+    spec, sd, kw = _oracle_unet("model_tiny.yaml", 1)
+    model = lambda x, t, labels: unet_forward(sd, x, t, labels, **kw)
+    image, mask = torch.from_numpy(g["image"]), torch.from_numpy(g["mask"])
+    none = iter(())
+    tr = RefTranslation(RefScheduler("ddim"), 2, sample_steps=50, eta=0.01, randn=lambda shape: next(none))
+    tgt = tr.process_label(1, 2)
+    latent = tr.inverse_diffusion(model, image, tgt, inverse_step=int(g["inversion/inverse_step"]))
+    ref_latent = torch.from_numpy(g["inversion/latent"])
+    assert rel_err(latent, ref_latent) < 1e-4
+    draws = iter(torch.from_numpy(g["inversion/latent_only/draws"]))
+    tr = RefTranslation(RefScheduler("ddim"), 2, sample_steps=50, eta=0.01, randn=lambda shape: next(draws))
+    out = tr.generate(model, eps_list=None, class_label=tgt, source_image=image, source_mask=mask,
+                      noise_initialize=ref_latent, start_from_step=-1)
+    assert float((out - torch.from_numpy(g["inversion/latent_only/out"])).abs().max()) < 2e-4
+    draws = iter(torch.from_numpy(g["inversion/both/draws"]))
+    tr = RefTranslation(RefScheduler("ddim"), 2, sample_steps=50, eta=0.01, randn=lambda shape: next(draws))
+    out = tr.generate(model, eps_list=torch.from_numpy(g["inversion/both/eps_list"]), class_label=tgt,
+                      source_image=image, source_mask=mask, noise_initialize=ref_latent,
+                      start_from_step=int(g["inversion/both/start"]))
+    assert float((out - torch.from_numpy(g["inversion/both/out"])).abs().max()) < 2e-4
