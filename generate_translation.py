@@ -45,8 +45,8 @@ def load_model(cfg, device, checkpoint, seed, precision):
     from mad_amd.model import build_model
     model = build_model(cfg, precision=precision)
     if checkpoint:
-        state = torch.load(checkpoint, map_location="cpu", weights_only=True)
-        model.load_state_dict(state.get("state_dict", state))
+        from mad_amd.checkpoint import load_checkpoint
+        load_checkpoint(model, checkpoint)           # EMA weights by position if present, else by name
     else:
         model.unet.init_seeded(seed)
     return model.to(device).eval()

@@ -13,6 +13,7 @@ _LAZY = {
     "CustomDDPMScheduler": "scheduler", "CustomDDIMScheduler": "scheduler",
     "create_cfg": "config", "merge_possible_with_base": "config", "load_cfg": "config",
     "spec_from_cfg": "unet_spec", "seeded_state_dict": "init",
+    "load_checkpoint": "checkpoint", "copy_parameters": "checkpoint",
 }
 
 

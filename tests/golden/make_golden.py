@@ -464,9 +464,31 @@ def refine_and_inversion_goldens():
     np.savez_compressed(os.path.join(HERE, "trajectory_refine.npz"), **out)
 
 
+def param_order_golden():
+    """param_order.json: ``named_parameters()`` order of the reference module per config.  The
+    reference restores EMA weights BY POSITION (``copy_parameters(shadow_params, model.parameters())``,
+    app.py:15-32), so a drop-in module must register its parameters in exactly this order."""
+    import json
+    install_placeholders()
+    sys.path.insert(0, REF)
+    import modeling.model as ref_model
+    from mad_amd.config import load_cfg
+    from mad_amd.unet_spec import spec_from_cfg
+    out = {}
+    for cfg_file in ("model_tiny.yaml", "model_64_64.yaml", "model_256_256.yaml"):
+        spec = spec_from_cfg(load_cfg(os.path.join(REPO, "configs", cfg_file)))
+        net = build_ref_unet(ref_model, spec, seed=1)
+        out[cfg_file] = [[n, list(p.shape)] for n, p in net.named_parameters()]
+    with open(os.path.join(HERE, "param_order.json"), "w") as f:
+        json.dump(out, f)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "refine":
         refine_and_inversion_goldens()
+    elif len(sys.argv) > 1 and sys.argv[1] == "params":
+        param_order_golden()
     else:
         main()
         refine_and_inversion_goldens()
+        param_order_golden()

@@ -123,3 +123,47 @@ def test_model_construction_and_state_dict_on_cpu():
     m.load_state_dict(want)
     with pytest.raises(RuntimeError, match="HIP kernels only"):
         m(torch.zeros(1, 3, 16, 16), torch.tensor([1.0]))
+
+
+def test_parameter_order_is_the_reference_order():
+    """The reference restores EMA weights by position (app.py:15-32): names, shapes and ORDER of
+    ``named_parameters()`` must equal the reference module's (fixture recorded from the reference)."""
+    import json
+    from mad_amd.config import load_cfg
+    from mad_amd.model import build_model
+    with open(os.path.join(REPO, "tests", "golden", "param_order.json")) as f:
+        want = json.load(f)
+    for cfg_file, ref in want.items():
+        m = build_model(load_cfg(os.path.join(REPO, "configs", cfg_file)))
+        mine = [[n, list(p.shape)] for n, p in m.unet.named_parameters()]
+        assert mine == ref, cfg_file
+
+
+def test_reference_format_checkpoint_loads(tmp_path):
+    """main.py:278-288 file layout: state_dict by name, EMA shadow_params by position."""
+    from mad_amd.checkpoint import load_checkpoint
+    from mad_amd.config import load_cfg
+    from mad_amd.init import seeded_state_dict
+    from mad_amd.model import build_model
+    cfg = load_cfg(os.path.join(REPO, "configs", "model_tiny.yaml"))
+    m = build_model(cfg)
+    raw, ema = seeded_state_dict(m.spec, 5), seeded_state_dict(m.spec, 6)
+    names = [n for n, _ in m.unet.named_parameters()]
+    path = str(tmp_path / "final.pth")
+    torch.save({"state_dict": raw, "optimizer": {}, "lr_scheduler": {}, "iter": 9,
+                "ema_state_dict": {"decay": 0.9999, "optimization_step": 10,
+                                   "shadow_params": [ema[n].clone() for n in names]}}, path)
+    info = load_checkpoint(m, path)                                  # EMA by position (app.py)
+    assert info == {"source": "ema_state_dict.shadow_params", "iter": 9}
+    got = m.state_dict()
+    assert all(torch.equal(got[n], ema[n]) for n in names)
+    info = load_checkpoint(m, path, use_ema=False)                   # by name (resume)
+    assert info["source"] == "state_dict"
+    got = m.state_dict()
+    assert all(torch.equal(got[n], raw[n]) for n in names)
+    torch.save(raw, path)                                            # a bare state_dict
+    m2 = build_model(cfg)
+    assert load_checkpoint(m2, path)["source"] == "state_dict"
+    torch.save({"ema_state_dict": {"shadow_params": [ema[n] for n in names[:-1]]}}, path)
+    with pytest.raises(AssertionError):
+        load_checkpoint(m2, path)
