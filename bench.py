@@ -33,6 +33,9 @@ def parse_args():
     p.add_argument("--batch", type=int, default=32, help="images per GPU per step")
     p.add_argument("--num-of-step", type=int, default=700,
                    help="start_from_step of the removal loop (reference default 700)")
+    p.add_argument("--workload", default="removal", choices=["removal", "transfer"],
+                   help="removal: domain_translation (headline); transfer: image_translation with inpainting and "
+                        "per-step component masks, S = 180 (a secondary configuration, not the headline)")
     p.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-evals", type=int, default=40, help="denoiser evaluations in the CPU sample")
@@ -129,7 +132,15 @@ def main():
     sampled = [0]
     model.unet.forward = counted
 
+    guides = synthetic_faces(B, R, seed=900 + rank).to(dev) if args.workload == "transfer" else None
+    if args.workload == "transfer":
+        from mad_amd.translation import MAX_STEP
+        S = MAX_STEP                                   # the transfer loop starts at its longest component step
+
     def one_step():
+        if args.workload == "transfer":
+            return td.image_translation(model, model, images, images, 1, 0, source_parsing_mask=maps, use_cam=True,
+                                        inpainting=True, inverse_image=guides)
         return td.domain_translation(model, model, images, source_class_label=0, target_class_label=1,
                                      parsing_mask=maps, start_from_step=S)
 
@@ -179,13 +190,18 @@ def main():
                 tj = json.load(f)
             traffic, traffic_src = tj.get("hbm_bytes_per_launch"), "profiles/pmc_halo_traffic.json (rocprofv3 --pmc FETCH_SIZE x2, WRITE_SIZE)"
         line = {
-            "metric": "translated images/sec @256x256, fixed-step inversion+denoise (makeup removal)"
-                      if R == 256 else f"translated images/sec @{R}x{R}, fixed-step inversion+denoise",
+            "metric": ("translated images/sec @256x256, fixed-step inversion+denoise (makeup removal)"
+                       if R == 256 else f"translated images/sec @{R}x{R}, fixed-step inversion+denoise")
+                      if args.workload == "removal" else
+                      f"translated images/sec @{R}x{R}, makeup transfer (inpainting + component masks)",
             "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
-            "config": {"workload": f"{os.path.basename(args.config)} makeup removal (noise encoding + regeneration), "
-                                   f"DDPM 1000-step table, start_from_step={S} ({evals} denoiser evaluations per "
+            "config": {"workload": f"{os.path.basename(args.config)} "
+                                   + ("makeup removal (noise encoding + regeneration), " if args.workload == "removal"
+                                      else "makeup transfer (noise encoding + regeneration from a synthetic guide, "
+                                           "inpainting with per-step component masks), ")
+                                   + f"DDPM 1000-step table, start_from_step={S} ({evals} denoiser evaluations per "
                                    f"image), batch {B} per GPU, random-init (seeded) weights",
                        "batch_per_gpu": B, "num_of_step": S, "resolution": R, "parallelism": f"dp{world}",
                        "denoiser_evals_per_s": world * B * args.steps * evals / elapsed / B,
