@@ -84,6 +84,41 @@ def cpu_baseline(cfg, spec, num_of_step, n_evals):
             "evals_per_s": 1.0 / per_eval}
 
 
+def hbm_kernels(dev, B, R, C, iters=20):
+    """Achieved GB/s of the bandwidth-bound kernels on the bench shapes (outside the timed region):
+    the sampler step (epsilon, x_t, z in, x_{t-1} out = 16 B per element, fp32) and the GroupNorm
+    statistics / apply passes (2 B read; 2 B read + 2 B write per bf16 element)."""
+    from mad_amd import ops
+    from mad_amd._lib import SamplerCoef
+
+    def timed(fn):
+        for _ in range(3):
+            fn()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        a.record()
+        for _ in range(iters):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) / iters * 1e-3
+
+    out = {}
+    eps, xt, z = (torch.randn(B, 3, R, R, device=dev) for _ in range(3))
+    c = SamplerCoef(algo=0, pred_type=0, op=0, clip=1, use_clipped=0, add_variance=1, known_noise=1,
+                    sqrt_a_t=0.8, sqrt_b_t=0.6, c0=0.1, c1=0.9, std=0.05, sqrt_a_prev=0.85, sqrt_b_prev=0.52,
+                    dir_coef=0.0, clip_range=1.0, eps_div=1.0)
+    t = timed(lambda: ops.sampler_update(c, eps, xt, noise=z))
+    out["sampler_step"] = {"GB/s": 16.0 * eps.numel() / t / 1e9, "bytes_per_element": 16, "us": t * 1e6}
+    x = torch.randn(B, R, R, C, device=dev).to(torch.bfloat16)
+    coef = torch.rand(B, C, 2, device=dev)
+    t = timed(lambda: ops.gn_partial(x))
+    out["gn_partial"] = {"GB/s": 2.0 * x.numel() / t / 1e9, "bytes_per_element": 2, "us": t * 1e6}
+    t = timed(lambda: ops.gn_apply(x, coef, act=True))
+    out["gn_apply"] = {"GB/s": 4.0 * x.numel() / t / 1e9, "bytes_per_element": 4, "us": t * 1e6}
+    return out
+
+
 def main():
     args = parse_args()
     rank = int(os.environ.get("RANK", "0"))
@@ -215,6 +250,7 @@ def main():
                          "avg_launch_ms": conv["ms"] / conv["launches"] if conv["launches"] else None,
                          "mfma_kernels": per_kernel},
         }
+        line["hbm_kernels"] = hbm_kernels(dev, B, R, spec.model_channels)
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(cfg, spec, S, args.cpu_evals)
         print(json.dumps(line), flush=True)
