@@ -4,7 +4,7 @@
  * The reference has no FFI of its own for this path: it is pure Python calling torch operators
  * (cuDNN / cuBLAS / xformers behind them).  Each entry point below therefore names the reference
  * operator site (file:line under /root/reference) whose arithmetic it replaces; a binding for it
- * is a few lines of ctypes.
+ * is a few lines of ctypes (mad_amd/_lib.py holds the full signature table).
  *
  * Conventions
  *   - every pointer is a device pointer owned by the caller; nothing here allocates or frees;
