@@ -49,6 +49,12 @@ template <typename T> struct Vec16 {
     uint4 raw;
     __device__ __forceinline__ void load(const T* p) { raw = *reinterpret_cast<const uint4*>(p); }
     __device__ __forceinline__ void store(T* p) const { *reinterpret_cast<uint4*>(p) = raw; }
+    // streaming store: the line is not expected to be re-read by this kernel
+    __device__ __forceinline__ void store_nt(T* p) const {
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        u32x4 v = {raw.x, raw.y, raw.z, raw.w};
+        __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(p));
+    }
     __device__ __forceinline__ void unpack(float* f) const {
         const T* e = reinterpret_cast<const T*>(&raw);
 #pragma unroll

@@ -33,6 +33,7 @@ struct HaloArgs {
     // optional 1x1 projection of a second input added to the result (extra K-tiles, centre tap only)
     const void* sx1; const void* sx2; const void* sw;
     int SC1, SC2;
+    int stream_out;   // output larger than the on-die caches: written with streaming stores
 };
 
 constexpr int HT = 16;                 // output tile edge
@@ -484,7 +485,8 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / 2) void conv3x3_halo_kernel
                 for (int i = 0; i < VEC; ++i) v[i] = fmaf(s[i], 0.25f, v[i]);
             }
             Vec16<T> o; o.pack(v);
-            o.store(y + m * a.Cout + n0 + ec);
+            if (a.stream_out) o.store_nt(y + m * a.Cout + n0 + ec);     // larger than the caches: do not allocate
+            else o.store(y + m * a.Cout + n0 + ec);
             if (a.stats) {
                 float f[VEC]; o.unpack(f);          // statistics of the values as stored
 #pragma unroll
@@ -576,6 +578,7 @@ static int conv3x3_fused_impl(const void* x1, int C1, const void* x2, int C2, co
     a.Hs = upsample ? H / 2 : H; a.Ws = upsample ? W / 2 : W;
     a.tiles_x = W / HT; a.tiles_y = H / HT;
     a.sx1 = sx1; a.sx2 = SC2 ? sx2 : sx1; a.sw = sw; a.SC1 = SC1; a.SC2 = SC2;
+    a.stream_out = (size_t)B * H * W * Cout * (dtype == MAD_BF16 ? 2 : 4) > ((size_t)256 << 20);
     hipStream_t s = (hipStream_t)stream;
     const char* what = "mad_conv3x3_fused";
     // 128 output channels per workgroup unless that leaves the chip (256 CUs, two workgroups each)
@@ -637,7 +640,7 @@ extern "C" int mad_conv_out_fused(const void* x, int Cin, const float* coef, int
     a.x1 = x; a.x2 = x; a.w = w; a.bias = bias; a.coef = coef; a.residual = nullptr; a.y = y; a.stats = nullptr;
     a.C1 = Cin; a.C2 = 0; a.B = B; a.H = H; a.W = W; a.Cout = Cout; a.upsample = 0; a.res_mode = MAD_RES_NONE;
     a.act = act; a.Hs = H; a.Ws = W;
-    a.sx1 = a.sx2 = a.sw = nullptr; a.SC1 = a.SC2 = 0;
+    a.sx1 = a.sx2 = a.sw = nullptr; a.SC1 = a.SC2 = 0; a.stream_out = 0;
     a.tiles_x = W / HT; a.tiles_y = H / HT; a.ntiles_n = 1;
     hipStream_t s = (hipStream_t)stream;
     const char* what = "mad_conv_out_fused";
