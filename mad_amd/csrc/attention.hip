@@ -24,8 +24,11 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(const T* __restrict_
     constexpr int ROW = AttnLds<T>::ROW;          // bytes per key row in LDS
     constexpr int CHUNKS = ROW / 16;              // 16-byte chunks per row
     constexpr int NT = NW * 64;
+    // bf16 V rows sit at a 192-byte pitch: the four key rows of a transposed 4x16 block read then fall
+    // on disjoint bank ranges (row pitch 48 dwords -> banks 0, 48, 32, 16)
+    constexpr int VROW = sizeof(T) == 2 ? 192 : ROW;
     __shared__ __attribute__((aligned(16))) unsigned char k_lds[KT * ROW];
-    __shared__ __attribute__((aligned(16))) unsigned char v_lds[KT * ROW];
+    __shared__ __attribute__((aligned(16))) unsigned char v_lds[KT * VROW];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.z, head = blockIdx.y;
@@ -57,18 +60,37 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(const T* __restrict_
     for (int e = 0; e < 16; ++e) { o[0][e] = 0.0f; o[1][e] = 0.0f; }
     float m_run = -1.0e30f, l_run = 0.0f;
 
+    // K/V tile staging: global -> registers one tile ahead of the LDS copy, so the global latency of
+    // tile t+1 is covered by the products of tile t
+    constexpr int PER_THREAD = (KT * CHUNKS + NT - 1) / NT;
+    uint4 kreg[PER_THREAD], vreg[PER_THREAD];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < PER_THREAD; ++i) {
+            const int c = tid + i * NT;
+            if (c < KT * CHUNKS) {
+                const int r = c / CHUNKS, ch = c % CHUNKS;
+                const T* krow = base + (size_t)(k0 + r) * C3 + HD;
+                kreg[i] = *reinterpret_cast<const uint4*>(krow + ch * VEC);
+                vreg[i] = *reinterpret_cast<const uint4*>(krow + HD + ch * VEC);
+            }
+        }
+    };
+    fetch(0);
     for (int k0 = 0; k0 < L; k0 += KT) {
         __syncthreads();   // previous tile fully consumed
-        for (int c = tid; c < KT * CHUNKS; c += NT) {
-            const int r = c / CHUNKS, ch = c % CHUNKS;
-            const T* krow = base + (size_t)(k0 + r) * C3 + HD;
-            const uint4 kv = *reinterpret_cast<const uint4*>(krow + ch * VEC);
-            const uint4 vv = *reinterpret_cast<const uint4*>(krow + HD + ch * VEC);
-            const int sw = (ROW == 128) ? (ch ^ ((r >> 1) & 7)) : (ch ^ (r & 15));
-            *reinterpret_cast<uint4*>(k_lds + r * ROW + sw * 16) = kv;
-            *reinterpret_cast<uint4*>(v_lds + r * ROW + ch * 16) = vv;
+#pragma unroll
+        for (int i = 0; i < PER_THREAD; ++i) {
+            const int c = tid + i * NT;
+            if (c < KT * CHUNKS) {
+                const int r = c / CHUNKS, ch = c % CHUNKS;
+                const int sw = (ROW == 128) ? (ch ^ ((r >> 1) & 7)) : (ch ^ (r & 15));
+                *reinterpret_cast<uint4*>(k_lds + r * ROW + sw * 16) = kreg[i];
+                *reinterpret_cast<uint4*>(v_lds + r * VROW + ch * 16) = vreg[i];
+            }
         }
         __syncthreads();
+        if (k0 + KT < L) fetch(k0 + KT);
 
         // S^T[key][query] = sum_d K[key][d] * Q[query][d]
         f32x16 s;
@@ -108,14 +130,19 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(const T* __restrict_
                 for (int j = 0; j < 8; ++j) pf[j] = (__bf16)s[8 * st + j];
 #pragma unroll
                 for (int dh = 0; dh < 2; ++dh) {
-                    bf16x8 vf;
-                    const int d = dh * 32 + qi;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const int key = 16 * st + 8 * (j >> 2) + 4 * fh + (j & 3);
-                        const unsigned short bits = *reinterpret_cast<const unsigned short*>(v_lds + key * ROW + d * 2);
-                        vf[j] = __builtin_bit_cast(__bf16, bits);
-                    }
+                    // A fragment = V^T[d][key]: two hardware-transposed reads of a 4-key x 16-d block each.
+                    // In a 16-lane group lane 4q+p supplies the address of key row q, d columns 4p..4p+3,
+                    // and lane i receives column i of the four rows.
+                    const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+                    const int dcol = dh * 32 + (g & 1) * 16 + 4 * pp;
+                    const int krow0 = 16 * st + 4 * (g >> 1) + q;
+                    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+                    typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+                    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                        (lds_bf16x4*)(v_lds + krow0 * VROW + dcol * 2));
+                    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                        (lds_bf16x4*)(v_lds + (krow0 + 8) * VROW + dcol * 2));
+                    const bf16x8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                     o[dh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[dh], 0, 0, 0);
                 }
             }

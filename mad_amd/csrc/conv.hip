@@ -476,8 +476,8 @@ template <typename T, int BM, int BN, int NST> static int launch_igemm(ConvArgs 
     return check_launch("mad_conv2d");
 }
 
-// Tile choice: 128x128 tiles when they fill the chip at least once; otherwise 64x64 tiles with a
-// deeper ring, which quadruples the number of workgroups of the small late-stage layers.
+// Tile choice: 128x128 tiles when they fill the chip at least once; else 64x128 if those do; otherwise
+// 64x64 tiles with a deeper ring, which quadruples the number of workgroups of the small late-stage layers.
 template <typename T> static int dispatch_igemm(const ConvArgs& a, hipStream_t s) {
     const char* force = getenv("MAD_IGEMM_TILE");      // tuning aid: "128x128x2", "64x64x4", ...
     const std::string f = force ? force : "";
@@ -490,6 +490,7 @@ template <typename T> static int dispatch_igemm(const ConvArgs& a, hipStream_t s
     if (f == "64x64x4") return launch_igemm<T, 64, 64, 4>(a, s);
     if (f == "64x128x3" && wide) return launch_igemm<T, 64, 128, 3>(a, s);
     if (wide && big_blocks >= 256) return launch_igemm<T, 128, 128, 2>(a, s);
+    if (wide && ((a.M + 63) / 64) * (a.Cout / 128) >= 256) return launch_igemm<T, 64, 128, 3>(a, s);
     if (!wide && ((a.M + 127) / 128) * (a.Cout / 64) >= 256) return launch_igemm<T, 128, 64, 2>(a, s);
     return launch_igemm<T, 64, 64, 4>(a, s);
 }

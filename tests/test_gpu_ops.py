@@ -174,7 +174,7 @@ CONV_CASES = [
 
 @pytest.mark.parametrize("case", CONV_CASES)
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("tile", ["auto", "128x128x2", "128x64x2"])
+@pytest.mark.parametrize("tile", ["auto", "128x128x2", "128x64x2", "64x128x3"])
 def test_conv2d(dev, case, dt, tile, monkeypatch):
     """Every block-tile variant the dispatcher can pick (small inputs alone would only reach 64x64)."""
     from mad_amd import _lib, ops

@@ -7,11 +7,14 @@ from mad_amd import ops
 from bench_conv import timeit
 
 dev = torch.device("cuda:0")
-B = 32
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 # (H, Cin, Cout, ksize)
 shapes = [(8, 512, 512, 3), (8, 1024, 512, 3), (8, 512, 512, 1), (8, 512, 1536, 1), (16, 512, 512, 1),
           (16, 512, 1536, 1), (32, 256, 768, 1), (32, 256, 256, 1), (64, 512, 256, 1), (128, 256, 128, 1),
           (256, 256, 128, 1), (16, 512, 512, 3)]
+if B == 64:      # the 64x64 model's shapes
+    shapes = [(8, 768, 768, 3), (8, 1536, 768, 3), (8, 768, 768, 1), (8, 768, 2304, 1), (16, 576, 576, 1),
+              (16, 576, 1728, 1), (32, 384, 1152, 1), (32, 384, 384, 1)]
 tiles = ["128x128x2", "128x128x3", "128x64x2", "128x64x3", "64x128x3", "64x64x4"]
 for H, Cin, Cout, k in shapes:
     x = (torch.randn(B, H, H, Cin, device=dev) * 0.7).to(torch.bfloat16)
