@@ -214,3 +214,21 @@ def test_inversion_start_matches_reference(dev):
                       source_image=image.clone(), source_mask=mask, noise_initialize=ref_latent.to(dev),
                       start_from_step=int(g["inversion/both/start"]))
     assert float((out - torch.from_numpy(g["inversion/both/out"])).abs().max()) < 5e-4
+
+
+@pytest.mark.parametrize("precision,tol", [("fp32", 1e-4), ("bf16", 3e-2)])
+def test_full_size_batch_consistency(dev, precision, tol):
+    """At the bench size (256x256 model, batch 32) the kernel variants chosen differ from those a
+    single image gets (wide / narrow workgroups, implicit-GEMM tiles).  Every op on the path is
+    per-sample, so each image of the batch must come out as it does alone; and a repeat is bit-identical."""
+    cfg, m = _model("model_256_256.yaml", precision, 1, dev)
+    g = torch.Generator(device="cpu").manual_seed(11)
+    x = torch.randn(32, 3, 256, 256, generator=g).to(dev)
+    lab = torch.eye(2, device=dev)[torch.arange(32, device=dev) % 2]
+    t = torch.tensor([431.0], device=dev)
+    y = m(x, t, class_labels=lab)
+    assert torch.isfinite(y).all()
+    assert torch.equal(y, m(x, t, class_labels=lab))
+    for i in (0, 13, 31):
+        yi = m(x[i:i + 1].contiguous(), t, class_labels=lab[i:i + 1].contiguous())
+        assert rel_err(y[i:i + 1].cpu(), yi.cpu()) < tol, i
