@@ -37,3 +37,31 @@ def test_generate_translation_cli(tmp_path):
     stamp = os.path.getmtime(out / "pred_0.png")
     gt.main(argv)                                                 # second run skips what exists
     assert os.path.getmtime(out / "pred_0.png") == stamp
+
+
+def test_generate_transfer_cli(tmp_path):
+    """Transfer entry point: paired lists, parsing maps found by the images -> parsing path rule,
+    guides from --guide-root, --inpainting --cam, one unreadable pair skipped."""
+    from PIL import Image
+    import generate_transfer as gtr
+    from mad_amd.synthetic import synthetic_faces, synthetic_parsing_map
+    img_dir, par_dir, guide_dir = tmp_path / "images", tmp_path / "parsing", tmp_path / "guides"
+    for d in (img_dir, par_dir, guide_dir):
+        d.mkdir()
+    faces = synthetic_faces(4, 16, seed=5)
+    for i in range(4):
+        arr = ((faces[i].permute(1, 2, 0).numpy() * 0.5 + 0.5) * 255).astype("uint8")
+        Image.fromarray(arr).save(img_dir / f"p{i}.png")
+        Image.fromarray(arr[::-1].copy()).save(guide_dir / f"p{i}.png")
+        Image.fromarray(synthetic_parsing_map(16, seed=i).numpy()).save(par_dir / f"p{i}.png")
+    (tmp_path / "src.txt").write_text("p0.png\np1.png\nnope.png\n")
+    (tmp_path / "tgt.txt").write_text("p2.png\np3.png\np2.png\n")
+    out = tmp_path / "out"
+    argv = ["--config", os.path.join(REPO, "configs", "model_tiny.yaml"), "--save-folder", str(out),
+            "--source-root", str(img_dir), "--target-root", str(img_dir), "--guide-root", str(guide_dir),
+            "--source-list", str(tmp_path / "src.txt"), "--target-list", str(tmp_path / "tgt.txt"),
+            "--source-label", "1", "--target-label", "0", "--inpainting", "--cam"]
+    gtr.main(argv)
+    assert sorted(os.listdir(out)) == ["pred_0.png", "pred_1.png"]
+    img = np.array(Image.open(out / "pred_1.png"))
+    assert img.shape == (16, 16, 3) and img.std() > 0
