@@ -174,6 +174,18 @@ int mad_conv3x3_fused_skip(const void* x1, int C1, const void* x2, int C2, const
                            int SC2, const void* sw, void* y, float* stats, int dtype, int B, int H, int W,
                            int Cout, void* stream);
 
+/* The same GroupNorm -> SiLU -> Conv2d(3x3) -> (+ residual) -> statistics fusion for the 8x8 layers
+ * (H = W = 8 is implied): one workgroup holds a whole image's input in LDS.  x is the concatenation of
+ * x1 (C1) and x2 (C2), NHWC (B,8,8,C); C1, C2 multiples of 64 (bf16) / 32 (fp32); Cout a multiple of 64.
+ * coef NULL: the input is used as it is.  res_mode MAD_RES_NONE, MAD_RES_SAME or MAD_RES_DOWN
+ * (residual (B,16,16,Cout), 2x2 mean).
+ * stats (may be NULL) is fp32 (B, 1, Cout, 2): per-image sum / sum of squares of y (nsplit = 1 for
+ * mad_gn_finalize).  Replaces model.py:341, 346-353 and the statistics of model.py:182-190 at the
+ * innermost resolution. */
+int mad_conv3x3_img8(const void* x1, int C1, const void* x2, int C2, const float* coef, int act,
+                     const void* w, const float* bias, const void* residual, int res_mode, void* y,
+                     float* stats, int dtype, int B, int Cout, void* stream);
+
 /* GroupNorm statistics, pass 1: per-(sample, split, channel) sum and sum of squares over the
  * split's pixels of the concatenation of x1 (C1) and x2 (C2).  partial is fp32
  * (B, nsplit, C1+C2, 2).  HW must be a multiple of nsplit. */

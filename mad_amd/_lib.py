@@ -52,6 +52,8 @@ SIGNATURES = {
     "mad_conv3x3_fused_skip": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p,
                                        c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p] + [c_int] * 5 +
                                [c_void_p]),
+    "mad_conv3x3_img8": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int,
+                                 c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "mad_gn_partial": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
     "mad_gn_finalize": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int,
                                 c_void_p, c_int, c_int, c_int, c_float, c_void_p]),

@@ -19,6 +19,8 @@ from __future__ import annotations
 
 from typing import Dict, List, Optional
 
+import os
+
 import torch
 from torch import nn
 
@@ -28,6 +30,7 @@ from .unet_spec import GN_EPS, BlockSpec, UNetSpec, build_spec, gn_groups, spec_
 
 Tensor = torch.Tensor
 LOADER_NORM_MIN_RES = 16      # 3x3 convs above this resolution apply GroupNorm+SiLU in their loader
+IMG8_CONV = os.environ.get("MAD_IMG8", "1") != "0"   # 8x8 layers on the image-resident kernel (0: implicit GEMM)
 
 
 class _Params(nn.Module):
@@ -229,6 +232,18 @@ class DhariwalUNet(nn.Module):
                 y, part = ops.conv3x3_fused(h, e["conv1.w"], bias1, coef=None, residual=res,
                                             res_mode=mode, want_stats=True, skip=proj)
             out = _Act(y, part)
+        elif IMG8_CONV and ops.img8_conv_pays(xt.shape[0], b.out_channels) and ops.img8_conv_ok(b.res_out, b.res_out, b.in_channels if b.down else xt.shape[3],
+                                            0 if (b.down or st is None) else st.shape[3], b.out_channels, xt.dtype):
+            # innermost resolution: whole-image workgroups, norm+SiLU in the loader, statistics per image
+            if b.down:
+                h = ops.gn_apply(xt, c0, act=True, x2=st, pool=True)
+                h, part = ops.conv3x3_img8(h, e["conv0.w"], e["conv0.b"], want_stats=True)
+            else:
+                h, part = ops.conv3x3_img8(xt, e["conv0.w"], e["conv0.b"], coef=c0, act=True, x2=st, want_stats=True)
+            c1 = ops.gn_finalize(part, hw_out, e["norm1.g"], e["norm1.b"], gn_groups(b.out_channels), GN_EPS,
+                                 ada=ada_v, ada_stride=ada_total)
+            out = _Act(*ops.conv3x3_img8(h, e["conv1.w"], e["conv1.b"], coef=c1, act=True, residual=res,
+                                         res_mode=mode, want_stats=True))
         else:
             stats_ok = hw_out % 64 == 0       # the implicit GEMM's epilogue can then take the statistics
             h = ops.gn_apply(xt, c0, act=True, x2=st, pool=b.down)

@@ -321,6 +321,52 @@ def conv3x3_fused(x1: Tensor, w: Tensor, bias: Optional[Tensor], coef: Optional[
     return (y, stats) if want_stats else y
 
 
+def conv3x3_img8(x1: Tensor, w: Tensor, bias: Optional[Tensor], coef: Optional[Tensor] = None, act: bool = True,
+                 x2: Optional[Tensor] = None, residual: Optional[Tensor] = None, res_mode: int = _lib.RES_NONE,
+                 want_stats: bool = False):
+    """3x3 conv of an 8x8 layer with the whole image resident in LDS: the input's GroupNorm(+SiLU) from
+    ``coef`` (B,C,2) or None, an optional residual (same shape, or 16x16 averaged 2x2 with RES_DOWN), and
+    per-image output statistics (B,1,Cout,2)."""
+    _dev(x1, x2, w, bias, coef, residual)
+    B, H, W_, C1 = x1.shape
+    C2 = 0 if x2 is None else x2.shape[3]
+    Cout = w.shape[0]
+    if (H, W_) != (8, 8) or (x2 is not None and tuple(x2.shape[:3]) != (B, 8, 8)):
+        raise ValueError(f"conv3x3_img8 takes 8x8 images, got {tuple(x1.shape)}")
+    if w.dtype != x1.dtype or tuple(w.shape) != (Cout, 3, 3, C1 + C2):
+        raise ValueError(f"conv3x3_img8 weight {tuple(w.shape)}/{w.dtype} does not match input {C1}+{C2}/{x1.dtype}")
+    if coef is not None and (coef.dtype != torch.float32 or tuple(coef.shape) != (B, C1 + C2, 2)):
+        raise ValueError("conv3x3_img8 coef must be fp32 (B, C, 2)")
+    if residual is not None:
+        want = {_lib.RES_SAME: (B, 8, 8, Cout), _lib.RES_DOWN: (B, 16, 16, Cout)}.get(res_mode)
+        if want is None or tuple(residual.shape) != want or residual.dtype != x1.dtype:
+            raise ValueError(f"conv3x3_img8 residual {tuple(residual.shape)} does not fit mode {res_mode}")
+    elif res_mode != _lib.RES_NONE:
+        raise ValueError("res_mode set without a residual tensor")
+    y = torch.empty((B, 8, 8, Cout), dtype=x1.dtype, device=x1.device)
+    stats = torch.empty((B, 1, Cout, 2), dtype=torch.float32, device=x1.device) if want_stats else None
+    end = TIMER.bracket("conv3x3_img8", 2.0 * B * 64 * Cout * (C1 + C2) * 9)
+    check(lib.mad_conv3x3_img8(_ptr(x1), C1, _ptr(x2), C2, _ptr(coef), int(act), _ptr(w), _ptr(bias), _ptr(residual),
+                               res_mode, _ptr(y), _ptr(stats), _dtype_code(x1), B, Cout, _stream()),
+          "mad_conv3x3_img8")
+    if end is not None:
+        end.record()
+    return (y, stats) if want_stats else y
+
+
+def img8_conv_ok(H: int, W_: int, C1: int, C2: int, Cout: int, dtype) -> bool:
+    """Shapes the image-resident 8x8 kernel covers."""
+    ck = 64 if dtype == torch.bfloat16 else 32
+    return (H, W_) == (8, 8) and C1 % ck == 0 and C2 % ck == 0 and Cout % 64 == 0
+
+
+def img8_conv_pays(B: int, Cout: int) -> bool:
+    """The image-resident kernel runs one workgroup per (image, 64 output channels) and one workgroup per
+    CU; past about one and a half rounds of the 256 CUs the implicit GEMM's larger tiles (each weight
+    byte reused by more pixels) are faster."""
+    return B * (Cout // 64) <= 384
+
+
 def fused_conv_ok(H: int, W_: int, Cout: int) -> bool:
     """Shapes the halo-tile kernel covers."""
     return H % 16 == 0 and W_ % 16 == 0 and H >= 16 and W_ >= 16 and Cout % 64 == 0

@@ -399,6 +399,58 @@ def test_conv3x3_fused_projection(dev, case, dt, bn, monkeypatch):
     assert rel_err(got[..., 1], (yf * yf).sum((1, 2)).cpu()) < 1e-4
 
 
+IMG8_CASES = [
+    # B, C1, C2, Cout, fuse, res
+    (3, 64, 0, 64, False, "none"),        # one K-tile (bf16) / two (fp32) per tap, a single slab
+    (2, 512, 512, 128, True, "same"),     # two full bf16 slabs from two sources
+    (2, 192, 128, 192, True, "none"),     # sources meet inside a slab; ragged last slab in fp32
+    (5, 768, 768, 64, True, "same"),      # three slabs, second source starts mid-slab
+    (2, 320, 0, 128, False, "down"),      # residual averaged from 16x16
+    (1, 576, 0, 64, True, "down"),        # second slab of one K-tile (bf16): ring restarts with nk = 9
+]
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", IMG8_CASES)
+def test_conv3x3_img8(dev, case, dt):
+    """Image-resident 8x8 conv against an fp64 reference; statistics against the stored output."""
+    from mad_amd import _lib, ops
+    B, C1, C2, Cout, fuse, res = case
+    C = C1 + C2
+    x = _rand((B, C, 8, 8), 1, 1.2)
+    w = _rand((Cout, C, 3, 3), 2, 1.0 / math.sqrt(C * 9))
+    bias = _rand((Cout,), 3)
+    coef = torch.stack([1 + 0.3 * _rand((B, C), 4), 0.3 * _rand((B, C), 5)], dim=-1) if fuse else None
+    q = (lambda t: t.to(dt).float()) if dt == torch.bfloat16 else (lambda t: t)
+    hin = q(x)
+    if fuse:
+        hin = q(F.silu(hin * coef[:, :, 0, None, None] + coef[:, :, 1, None, None]))
+    want = F.conv2d(hin.double(), q(w).double(), bias.double(), padding=1)
+    r, mode = None, _lib.RES_NONE
+    if res == "same":
+        r, mode = _rand((B, Cout, 8, 8), 6), _lib.RES_SAME
+        want = want + q(r).double()
+    elif res == "down":
+        r, mode = _rand((B, Cout, 16, 16), 6), _lib.RES_DOWN
+        want = want + F.avg_pool2d(q(r).double(), 2)
+    xn = _nhwc(x, dt, dev)
+    y, stats = ops.conv3x3_img8(xn[..., :C1].contiguous(), w.permute(0, 2, 3, 1).contiguous().to(dt).to(dev),
+                                bias.to(dev), coef=None if coef is None else coef.to(dev), act=True,
+                                x2=xn[..., C1:].contiguous() if C2 else None,
+                                residual=None if r is None else _nhwc(r, dt, dev), res_mode=mode, want_stats=True)
+    assert rel_err(_nchw(y), want) < (2e-5 if dt == torch.float32 else 8e-3)
+    yf = y.float()
+    got = stats.sum(1).cpu()
+    assert tuple(stats.shape) == (B, 1, Cout, 2)
+    assert rel_err(got[..., 0], yf.sum((1, 2)).cpu()) < 1e-4
+    assert rel_err(got[..., 1], (yf * yf).sum((1, 2)).cpu()) < 1e-4
+    # same values as the implicit-GEMM path on the same (already activated) input, up to summation order
+    hin_n = _nhwc(hin, dt, dev)
+    y2 = ops.conv2d(hin_n, w.permute(0, 2, 3, 1).contiguous().to(dt).to(dev), bias.to(dev),
+                    residual=None if r is None else _nhwc(r, dt, dev), res_mode=mode)
+    assert rel_err(y.float(), y2.float()) < (2e-5 if dt == torch.float32 else 6e-3)
+
+
 V2_CASES = [
     # B, H, C1, C2, Cout, fuse, up, res, stats
     (2, 64, 128, 0, 128, True, False, "none", True),      # one tile per workgroup: prologue + drain only
