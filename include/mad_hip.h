@@ -216,6 +216,29 @@ int mad_gn_apply(const void* x1, int C1, const void* x2, int C2, const float* co
  * softmax(q.k/8) in fp32.  Replaces model.py:357-375 / AttentionOp (model.py:199-212). */
 int mad_attention(const void* qkv, void* out, int dtype, int B, int L, int heads, void* stream);
 
+/* ------------------------------------------------------------------ training step --------- */
+/* The reference trains through torch autograd (main.py:239-254); these are the gradient kernels of the
+ * same operators.  Buffers named `workspace` are caller-owned device scratch of at least the size the
+ * matching *_workspace() query returns. */
+
+/* Weight gradient of a stride-1 convolution (ksize 1 or 3, pad ksize/2):
+ *   dw[co][ci][ky][kx] (+)= sum_{b,y,x} dy[b,y,x,co] * x[b, y+ky-pad, x+kx-pad, ci]
+ * x NHWC (B,H,W,Cin) -- or (B,H/2,W/2,Cin) read through a nearest x2 when `upsample` -- and dy NHWC
+ * (B,H,W,Cout) in `dtype`; dw fp32 in the (Cout,Cin,k,k) layout of the master weights.  bf16 with Cin a
+ * multiple of 32, Cout of 8 and (H % 8 == 0, W % 16 == 0, or H = W = 8) runs on MFMA; anything else on a
+ * generic vector-ALU kernel.  Partial sums are added in a fixed order (deterministic).
+ * Autograd of Conv2d.forward (model.py:135-166) with respect to `weight`. */
+size_t mad_conv_wgrad_workspace(int dtype, int B, int H, int W, int Cin, int Cout, int ksize);
+int mad_conv_wgrad(const void* x, const void* dy, float* dw, void* workspace, size_t workspace_bytes,
+                   int dtype, int B, int H, int W, int Cin, int Cout, int ksize, int upsample,
+                   int accumulate, void* stream);
+
+/* dbias[c] (+)= sum over rows of dy (rows, C): the bias gradient of a convolution or linear layer
+ * (model.py:164-165, 62-63). */
+size_t mad_bias_grad_workspace(int C);
+int mad_bias_grad(const void* dy, int dtype, long rows, int C, float* dbias, void* workspace,
+                  size_t workspace_bytes, int accumulate, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

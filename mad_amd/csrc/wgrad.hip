@@ -1,0 +1,296 @@
+// Weight gradients of the convolutions (training step): dW[co][ky][kx][ci] = sum over (b, y, x) of
+// dY[b,y,x,co] * X[b, y+ky-pad, x+kx-pad, ci], and the bias gradient (column sums of dY).
+//
+// The product reduces over PIXELS, while both operands are stored channels-last (a pixel's channels are
+// contiguous).  MFMA operands need the reduction index contiguous per lane, so the tiles are staged in
+// LDS as they lie in memory ([pixel][channel]) and read with the hardware-transposed LDS read
+// (ds_read_b64_tr_b16): a 16-lane group fetches a 4-pixel x 16-channel block and lane i receives channel
+// i of the four pixels.  Two such reads give the 8 reduction elements of a v_mfma_f32_32x32x16_bf16
+// operand; A (dY) and B (X) use the same pixel order inside a 16-pixel step.
+//
+// One workgroup owns a (128 output channels) x (32 input channels) x (all taps) slice of dW and walks a
+// strided share of the pixel tiles (8 rows x 16 columns of one image, or two 8x8 images); wave w keeps
+// the 32 output channels 32w.. of every tap in registers (9 accumulators).  The input halo of a tile is
+// staged once and the taps read it at shifted pixel offsets.  Workgroups that share a slice write their
+// sums to separate partial buffers, which a second kernel adds in a fixed order (deterministic).
+#include "mma.h"
+
+namespace mad {
+
+struct WgradArgs {
+    const void* x; const void* dy; float* partial;
+    int B, H, W, Cin, Cout, ksplit, ntiles, upsample;
+};
+
+namespace wg {
+constexpr int TPIX = 128;                  // pixels per tile
+constexpr int YROW = 256;                  // bytes of dY per pixel in LDS: 128 bf16 output channels
+constexpr int XROW = 64;                   // bytes of X per halo pixel in LDS: 32 bf16 input channels
+constexpr int OFF_X = TPIX * YROW;         // 32 KiB
+constexpr int X_BYTES = 13 * 1024;         // up to 208 halo pixels
+constexpr int LDS_BYTES = OFF_X + X_BYTES;
+}  // namespace wg
+
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) bf16x4_t lds_bf16x4_t;
+
+__device__ __forceinline__ bf16x8 tr_frag(const unsigned char* lo, const unsigned char* hi) {
+    const bf16x4_t l = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)lo);
+    const bf16x4_t h = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)hi);
+    return bf16x8{l[0], l[1], l[2], l[3], h[0], h[1], h[2], h[3]};
+}
+
+// KS: 1 or 3.  SW: 16 = a tile is 8 rows x 16 columns of one image (H % 8 == 0, W % 16 == 0);
+//              8 = a tile is two whole 8x8 images.
+template <int KS, int SW>
+__global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs a) {
+    using namespace wg;
+    constexpr int PAD = KS / 2, NT = KS * KS;
+    constexpr int NIMG = 16 / SW, SH = 8;
+    constexpr int HPW = SW + 2 * PAD, HPH = SH + 2 * PAD, HPIX = NIMG * HPH * HPW;
+    constexpr int XPIECES = (HPIX + 15) / 16;
+    static_assert(XPIECES * 1024 <= X_BYTES, "halo region");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const unsigned lds0 = lds_addr(smem);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    const int ncic = a.Cin / 32;
+    const int ks = blockIdx.x % a.ksplit;
+    const int rest = blockIdx.x / a.ksplit;
+    const int ci0 = (rest % ncic) * 32, co0 = (rest / ncic) * 128;
+    const bf16_t* X = (const bf16_t*)a.x;
+    const bf16_t* DY = (const bf16_t*)a.dy;
+    const int Hs = a.upsample ? a.H >> 1 : a.H, Ws = a.upsample ? a.W >> 1 : a.W;
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.0f;
+
+    // transposed-read lane roles: group g = lane>>4 -> channel half (g&1), pixel half h = g>>1;
+    // inside the group lane 4q+pp addresses pixel q, channels 4pp..4pp+3
+    const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3, h = g >> 1;
+    const int a_lchunk = 4 * wave + (g & 1) * 2 + (pp >> 1);            // 16-byte chunk of this wave's 32 channels
+    const int a_off = ((a_lchunk ^ (q << 2)) << 4) + (pp & 1) * 8;      // chunk index XOR (pixel & 3) << 2
+    const int b_off = (g & 1) * 32 + pp * 8;
+    const int tpi = SW == 16 ? (a.H >> 3) * (a.W >> 4) : 1;             // tiles per image
+    const int tpr = SW == 16 ? (a.W >> 4) : 1;
+
+    for (int tile = ks; tile < a.ntiles; tile += a.ksplit) {
+        int b0, y0, x0;
+        if (SW == 16) { b0 = tile / tpi; const int r = tile - b0 * tpi; y0 = (r / tpr) * 8; x0 = (r % tpr) * 16; }
+        else { b0 = tile * 2; y0 = 0; x0 = 0; }
+        __syncthreads();                                 // the previous tile is consumed
+        // ---- dY: 32 pieces of 4 pixels x 256 bytes, chunk c of pixel p holds logical chunk c ^ ((p&3)<<2)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int piece = j * 4 + wave;
+            const int p = piece * 4 + (lane >> 4);
+            const int img = SW == 16 ? 0 : p >> 6;
+            const int py = SW == 16 ? p >> 4 : (p >> 3) & 7, px = SW == 16 ? p & 15 : p & 7;
+            const int lc = (lane & 15) ^ ((p & 3) << 2);
+            const int co = co0 + lc * 8;
+            const bool ok = (b0 + img) < a.B && co < a.Cout;            // Cout is a multiple of 8
+            const bf16_t* src = DY + ((size_t)((b0 + img) * a.H + y0 + py) * a.W + x0 + px) * a.Cout + co;
+            glds16(ok ? (const void*)src : (const void*)g_zero_page,
+                   __builtin_amdgcn_readfirstlane(lds0 + piece * 1024));
+        }
+        // ---- X halo: pieces of 16 halo pixels x 64 bytes
+        for (int piece = wave; piece < XPIECES; piece += 4) {
+            const int hp = piece * 16 + (lane >> 2);
+            const int img = hp / (HPH * HPW), r = hp - img * (HPH * HPW);
+            const int hy = r / HPW, hx = r - hy * HPW;
+            const int yy = y0 + hy - PAD, xx = x0 + hx - PAD;
+            const bool ok = hp < HPIX && (b0 + img) < a.B && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
+            const int sy = a.upsample ? yy >> 1 : yy, sx = a.upsample ? xx >> 1 : xx;
+            const bf16_t* src = X + ((size_t)((b0 + img) * Hs + sy) * Ws + sx) * a.Cin + ci0 + (lane & 3) * 8;
+            glds16(ok ? (const void*)src : (const void*)g_zero_page,
+                   __builtin_amdgcn_readfirstlane(lds0 + OFF_X + piece * 1024));
+        }
+        dma_wait_all();
+        __syncthreads();
+#pragma unroll 2
+        for (int s = 0; s < 8; ++s) {
+            const int pa = 16 * s + 4 * h + q;                           // tile pixel of the low half
+            const bf16x8 af = tr_frag(smem + pa * YROW + a_off, smem + (pa + 8) * YROW + a_off);
+            // halo pixel of (row, x) of this step at tap (0,0)
+            int hp_lo, hp_hi;
+            if (SW == 16) { hp_lo = s * HPW + 4 * h + q; hp_hi = hp_lo + 8; }
+            else { hp_lo = (s >> 2) * (HPH * HPW) + 2 * (s & 3) * HPW + 4 * h + q; hp_hi = hp_lo + HPW; }
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int sh = (t / KS) * HPW + (t % KS);
+                const bf16x8 bf = tr_frag(smem + OFF_X + (hp_lo + sh) * XROW + b_off,
+                                          smem + OFF_X + (hp_hi + sh) * XROW + b_off);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[t], 0, 0, 0);
+            }
+        }
+    }
+    // ---- partial[ks][co][tap][ci]
+    float* out = a.partial + (size_t)ks * a.Cout * NT * a.Cin;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int co = co0 + 32 * wave + acc_row(e, lane);
+            if (co < a.Cout) out[((size_t)co * NT + t) * a.Cin + ci0 + (lane & 31)] = acc[t][e];
+        }
+}
+
+// Generic (any channel counts, fp32 or bf16, strided operands) weight gradient on the vector ALU: the
+// first and last layers (3 image channels) and the fp32 mode.  One workgroup = one (co, tap) pair and a
+// share of the pixels; threads run over ci.  Element (b,y,x,c) of an operand is at b*sb + y*sy + x*sx + c*sc.
+struct WgradGenArgs {
+    const void* x; const void* dy; float* partial;
+    int B, H, W, Cin, Cout, ks, ksplit, upsample;
+    long xsb, xsy, xsx, xsc, ysb, ysy, ysx, ysc;
+};
+
+template <typename TX, typename TY>
+__global__ __launch_bounds__(256) void wgrad_generic_kernel(WgradGenArgs a) {
+    const int nt = a.ks * a.ks, pad = a.ks / 2;
+    const int split = blockIdx.x % a.ksplit;
+    const int rest = blockIdx.x / a.ksplit;
+    const int t = rest % nt, co = rest / nt;
+    const int ky = t / a.ks - pad, kx = t % a.ks - pad;
+    const TX* X = (const TX*)a.x;
+    const TY* DY = (const TY*)a.dy;
+    const long npix = (long)a.B * a.H * a.W;
+    for (int ci = threadIdx.x; ci < a.Cin; ci += 256) {
+        float s = 0.0f;
+        for (long p = split; p < npix; p += a.ksplit) {
+            const int x = (int)(p % a.W), y = (int)((p / a.W) % a.H), b = (int)(p / ((long)a.W * a.H));
+            const int yy = y + ky, xx = x + kx;
+            if (yy < 0 || yy >= a.H || xx < 0 || xx >= a.W) continue;
+            const int sy = a.upsample ? yy >> 1 : yy, sx = a.upsample ? xx >> 1 : xx;
+            const float g = Elem<TY>::load(DY[b * a.ysb + y * a.ysy + x * a.ysx + co * a.ysc]);
+            s = fmaf(g, Elem<TX>::load(X[b * a.xsb + sy * a.xsy + sx * a.xsx + ci * a.xsc]), s);
+        }
+        a.partial[(((size_t)split * a.Cout + co) * nt + t) * a.Cin + ci] = s;
+    }
+}
+
+// dst[i] (+)= sum over s of partial[s][i], in the order s = 0, 1, ...; optionally scattering from the
+// (Cout, taps, Cin) order of the partials to the (Cout, Cin, taps) order of the master weights.
+__global__ void wgrad_reduce_kernel(const float* partial, float* dst, size_t n, int nsplit, int accumulate, int taps,
+                                    int Cin) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.0f;
+    for (int k = 0; k < nsplit; ++k) s += partial[(size_t)k * n + i];
+    size_t o = i;
+    if (taps > 0) {                                       // i = (co*taps + t)*Cin + ci  ->  (co*Cin + ci)*taps + t
+        const size_t ci = i % Cin, r = i / Cin, t = r % taps, co = r / taps;
+        o = (co * Cin + ci) * taps + t;
+    }
+    dst[o] = accumulate ? dst[o] + s : s;
+}
+
+// Column sums of a (rows, C) matrix, rows split over blockIdx.y: partial[split][c].
+template <typename T> __global__ __launch_bounds__(256) void colsum_kernel(const T* x, float* partial, long rows, int C,
+                                                                           long sr, long sc) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.0f;
+    for (long r = blockIdx.y; r < rows; r += gridDim.y) s += Elem<T>::load(x[r * sr + c * sc]);
+    partial[(size_t)blockIdx.y * C + c] = s;
+}
+
+static int pick_ksplit(int slices, int ntiles) {
+    int k = (3 * 256 + slices - 1) / slices;             // about three workgroups per CU in total
+    if (k > ntiles) k = ntiles;
+    if (k > 64) k = 64;
+    return k < 1 ? 1 : k;
+}
+
+}  // namespace mad
+
+using namespace mad;
+
+static bool wgrad_mfma_ok(int dtype, int H, int W, int Cin, int Cout, int ksize) {
+    if (dtype != MAD_BF16 || Cin % 32 != 0 || Cout % 8 != 0) return false;
+    if (H == 8 && W == 8) return true;
+    return H % 8 == 0 && W % 16 == 0;
+}
+
+static int wgrad_ksplit(int dtype, int B, int H, int W, int Cin, int Cout, int ksize, int* ntiles_out) {
+    if (wgrad_mfma_ok(dtype, H, W, Cin, Cout, ksize)) {
+        const int ntiles = (H == 8 && W == 8) ? (B + 1) / 2 : B * (H / 8) * (W / 16);
+        if (ntiles_out) *ntiles_out = ntiles;
+        return pick_ksplit(((Cout + 127) / 128) * (Cin / 32), ntiles);
+    }
+    if (ntiles_out) *ntiles_out = 0;
+    int k = (1024 + Cout * ksize * ksize - 1) / (Cout * ksize * ksize);
+    return k < 1 ? 1 : (k > 256 ? 256 : k);
+}
+
+extern "C" size_t mad_conv_wgrad_workspace(int dtype, int B, int H, int W, int Cin, int Cout, int ksize) {
+    const int k = wgrad_ksplit(dtype, B, H, W, Cin, Cout, ksize, nullptr);
+    return (size_t)k * Cout * ksize * ksize * Cin * sizeof(float);
+}
+
+extern "C" int mad_conv_wgrad(const void* x, const void* dy, float* dw, void* workspace, size_t workspace_bytes,
+                              int dtype, int B, int H, int W, int Cin, int Cout, int ksize, int upsample,
+                              int accumulate, void* stream) {
+    MAD_REQUIRE(x && dy && dw && workspace, "mad_conv_wgrad: null pointer");
+    MAD_REQUIRE(dtype == MAD_BF16 || dtype == MAD_F32, "mad_conv_wgrad: bad dtype %d", dtype);
+    MAD_REQUIRE(ksize == 1 || ksize == 3, "mad_conv_wgrad: ksize %d not supported", ksize);
+    MAD_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "mad_conv_wgrad: bad shape");
+    MAD_REQUIRE(!upsample || (H % 2 == 0 && W % 2 == 0), "mad_conv_wgrad: upsample needs even H, W");
+    MAD_REQUIRE(workspace_bytes >= mad_conv_wgrad_workspace(dtype, B, H, W, Cin, Cout, ksize),
+                "mad_conv_wgrad: workspace of %zu bytes is too small", workspace_bytes);
+    hipStream_t s = (hipStream_t)stream;
+    const int nt = ksize * ksize;
+    int ntiles = 0;
+    const int ksplit = wgrad_ksplit(dtype, B, H, W, Cin, Cout, ksize, &ntiles);
+    if (wgrad_mfma_ok(dtype, H, W, Cin, Cout, ksize)) {
+        WgradArgs a;
+        a.x = x; a.dy = dy; a.partial = (float*)workspace; a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
+        a.ksplit = ksplit; a.ntiles = ntiles; a.upsample = upsample;
+        const dim3 grid(((Cout + 127) / 128) * (Cin / 32) * ksplit);
+        const bool small = H == 8 && W == 8;
+#define MAD_WG_LAUNCH(KS, SW) hipLaunchKernelGGL((wgrad_mfma_kernel<KS, SW>), grid, dim3(256), wg::LDS_BYTES, s, a)
+        if (ksize == 3) { if (small) MAD_WG_LAUNCH(3, 8); else MAD_WG_LAUNCH(3, 16); }
+        else { if (small) MAD_WG_LAUNCH(1, 8); else MAD_WG_LAUNCH(1, 16); }
+#undef MAD_WG_LAUNCH
+    } else {
+        WgradGenArgs a;
+        a.x = x; a.dy = dy; a.partial = (float*)workspace; a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
+        a.ks = ksize; a.ksplit = ksplit; a.upsample = upsample;
+        const int Hs = upsample ? H / 2 : H, Ws = upsample ? W / 2 : W;
+        a.xsc = 1; a.xsx = Cin; a.xsy = (long)Ws * Cin; a.xsb = (long)Hs * Ws * Cin;
+        a.ysc = 1; a.ysx = Cout; a.ysy = (long)W * Cout; a.ysb = (long)H * W * Cout;
+        const dim3 grid(Cout * nt * ksplit);
+        if (dtype == MAD_BF16) hipLaunchKernelGGL((wgrad_generic_kernel<bf16_t, bf16_t>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((wgrad_generic_kernel<float, float>), grid, dim3(256), 0, s, a);
+    }
+    if (int rc = check_launch("mad_conv_wgrad")) return rc;
+    const size_t n = (size_t)Cout * nt * Cin;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const float*)workspace,
+                       dw, n, ksplit, accumulate, nt, Cin);
+    return check_launch("mad_conv_wgrad (reduce)");
+}
+
+extern "C" size_t mad_bias_grad_workspace(int C) { return (size_t)256 * C * sizeof(float); }
+
+extern "C" int mad_bias_grad(const void* dy, int dtype, long rows, int C, float* dbias, void* workspace,
+                             size_t workspace_bytes, int accumulate, void* stream) {
+    MAD_REQUIRE(dy && dbias && workspace, "mad_bias_grad: null pointer");
+    MAD_REQUIRE(dtype == MAD_BF16 || dtype == MAD_F32, "mad_bias_grad: bad dtype %d", dtype);
+    MAD_REQUIRE(rows > 0 && C > 0, "mad_bias_grad: bad shape");
+    MAD_REQUIRE(workspace_bytes >= mad_bias_grad_workspace(C), "mad_bias_grad: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    const int splits = rows < 256 ? (int)rows : 256;
+    const dim3 grid((C + 255) / 256, splits);
+    if (dtype == MAD_BF16)
+        hipLaunchKernelGGL((colsum_kernel<bf16_t>), grid, dim3(256), 0, s, (const bf16_t*)dy, (float*)workspace, rows, C,
+                           (long)C, 1L);
+    else
+        hipLaunchKernelGGL((colsum_kernel<float>), grid, dim3(256), 0, s, (const float*)dy, (float*)workspace, rows, C,
+                           (long)C, 1L);
+    if (int rc = check_launch("mad_bias_grad")) return rc;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((C + 255) / 256), dim3(256), 0, s, (const float*)workspace, dbias,
+                       (size_t)C, splits, accumulate, 0, 1);
+    return check_launch("mad_bias_grad (reduce)");
+}

@@ -372,6 +372,50 @@ def fused_conv_ok(H: int, W_: int, Cout: int) -> bool:
     return H % 16 == 0 and W_ % 16 == 0 and H >= 16 and W_ >= 16 and Cout % 64 == 0
 
 
+# ------------------------------------------------------------------------------ training: gradients
+def conv_wgrad(x: Tensor, dy: Tensor, ksize: int, upsample: bool = False, out: Optional[Tensor] = None,
+               accumulate: bool = False) -> Tensor:
+    """Weight gradient of a stride-1 conv: x NHWC (B,H,W,Cin) (or (B,H/2,W/2,Cin) with ``upsample``), dy NHWC
+    (B,H,W,Cout); returns fp32 (Cout, Cin, k, k), the layout of the master weights (model.py:116-133)."""
+    _dev(x, dy, out)
+    B, H, W_, Cout = dy.shape
+    Cin = x.shape[3]
+    want = (B, H // 2, W_ // 2, Cin) if upsample else (B, H, W_, Cin)
+    if tuple(x.shape) != want or x.dtype != dy.dtype:
+        raise ValueError(f"conv_wgrad: input {tuple(x.shape)}/{x.dtype} does not fit dy {tuple(dy.shape)}/{dy.dtype}")
+    if out is None:
+        out = torch.empty((Cout, Cin, ksize, ksize), dtype=torch.float32, device=x.device)
+        accumulate = False
+    elif tuple(out.shape) != (Cout, Cin, ksize, ksize) or out.dtype != torch.float32 or not out.is_contiguous():
+        raise ValueError("conv_wgrad: out must be contiguous fp32 (Cout, Cin, k, k)")
+    code = _dtype_code(x)
+    nbytes = lib.mad_conv_wgrad_workspace(code, B, H, W_, Cin, Cout, ksize)
+    ws = torch.empty((nbytes,), dtype=torch.uint8, device=x.device)
+    end = TIMER.bracket("conv_wgrad", 2.0 * B * H * W_ * Cout * Cin * ksize * ksize)
+    check(lib.mad_conv_wgrad(_ptr(x), _ptr(dy), _ptr(out), _ptr(ws), nbytes, code, B, H, W_, Cin, Cout, ksize,
+                             int(upsample), int(accumulate), _stream()), "mad_conv_wgrad")
+    if end is not None:
+        end.record()
+    return out
+
+
+def bias_grad(dy: Tensor, out: Optional[Tensor] = None, accumulate: bool = False) -> Tensor:
+    """Sum of dy (..., C) over every axis but the last, fp32 (C,)."""
+    _dev(dy, out)
+    C = dy.shape[-1]
+    rows = dy.numel() // C
+    if not dy.is_contiguous():
+        raise ValueError("bias_grad: dy must be contiguous")
+    if out is None:
+        out = torch.empty((C,), dtype=torch.float32, device=dy.device)
+        accumulate = False
+    nbytes = lib.mad_bias_grad_workspace(C)
+    ws = torch.empty((nbytes,), dtype=torch.uint8, device=dy.device)
+    check(lib.mad_bias_grad(_ptr(dy), _dtype_code(dy), rows, C, _ptr(out), _ptr(ws), nbytes, int(accumulate),
+                            _stream()), "mad_bias_grad")
+    return out
+
+
 # ------------------------------------------------------------------------------ GroupNorm
 def gn_nsplit(HW: int) -> int:
     return min(64, max(1, HW // 64))
