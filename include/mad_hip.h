@@ -239,6 +239,31 @@ size_t mad_bias_grad_workspace(int C);
 int mad_bias_grad(const void* dy, int dtype, long rows, int C, float* dbias, void* workspace,
                   size_t workspace_bytes, int accumulate, void* stream);
 
+/* Backward of h = act(GroupNorm(x)*(1+scale)+shift), in the three passes of the forward.  x is the
+ * concatenation of x1 (C1) and x2 (C2), NHWC (B,H,W,.); dy is the gradient with respect to h over all
+ * C1+C2 channels; coef is the forward's (a, d) table.  A gradient tensor's resolution mode: 0 = (H,W);
+ * 1 = (H/2,W/2), each pixel takes a quarter of its cell (h was 2x2-averaged afterwards);
+ * 2 = (2H,2W), each pixel takes the sum of its 2x2 block (h was upsampled afterwards).
+ *   partial:  gsum[b, split, c, 0/1] = sum over the split's pixels of g, g*x, with g = dy*act'(x*a+d)
+ *   finalize: from the forward's statistics partials (stat1/stat2 as in mad_gn_finalize) and gsum:
+ *             bcoef (B, C, 4) = (p, q, r, 0) with dx = g*p + x*q + r; dgb (B, 2C) = per-sample
+ *             [dgamma | dbeta] contributions (sum over b with mad_bias_grad); dada (may be NULL) laid out
+ *             like ada: dada[b*ada_stride + c] = dscale, [.. + C + c] = dshift
+ *   apply:    dx = g*p + x*q + r (+ add1 + add2, gradients reaching x by other branches, C1+C2 channels,
+ *             each with its own resolution mode), written as dx1 (B,H,W,C1) and dx2 (B,H,W,C2).
+ * Autograd of GroupNorm.forward + silu + addcmul (model.py:182-190, 341-348). */
+int mad_gn_bwd_partial(const void* x1, int C1, const void* x2, int C2, const void* dy, int dy_mode,
+                       const float* coef, int act, int dtype, float* gsum, int B, int H, int W,
+                       int nsplit, void* stream);
+int mad_gn_bwd_finalize(const float* stat1, int C1, int nsplit1, const float* stat2, int C2, int nsplit2,
+                        const float* gsum, int nsplit_g, const float* gamma, const float* beta,
+                        const float* ada, int ada_stride, float* bcoef, float* dgb, float* dada, int B,
+                        int groups, int HW, float eps, void* stream);
+int mad_gn_bwd_apply(const void* x1, int C1, const void* x2, int C2, const void* dy, int dy_mode,
+                     const float* coef, int act, const float* bcoef, const void* add1, int add1_mode,
+                     const void* add2, int add2_mode, void* dx1, void* dx2, int dtype, int B, int H,
+                     int W, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

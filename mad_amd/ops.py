@@ -416,6 +416,48 @@ def bias_grad(dy: Tensor, out: Optional[Tensor] = None, accumulate: bool = False
     return out
 
 
+GRAD_SAME, GRAD_FROM_HALF, GRAD_FROM_DOUBLE = 0, 1, 2     # resolution of a gradient tensor relative to x
+
+
+def gn_backward(x1: Tensor, dy: Tensor, coef: Tensor, stat1: Tensor, gamma: Tensor, beta: Tensor, groups: int,
+                eps: float, act: bool, x2: Optional[Tensor] = None, stat2: Optional[Tensor] = None,
+                ada: Optional[Tensor] = None, ada_stride: int = 0, dada: Optional[Tensor] = None,
+                dy_mode: int = GRAD_SAME, add1: Optional[Tensor] = None, add1_mode: int = GRAD_SAME,
+                add2: Optional[Tensor] = None, add2_mode: int = GRAD_SAME, need_dx: bool = True):
+    """Backward of h = act(GroupNorm([x1, x2]) * (1 + scale) + shift).
+
+    ``coef`` and ``stat1``/``stat2`` are the forward's (a, d) table and statistics partials; ``dy`` is the
+    gradient w.r.t. h (all channels, resolution per ``dy_mode``).  Returns (dx1, dx2, dgamma, dbeta); the
+    AdaGN gradients are written into ``dada`` (a view laid out like ``ada``).  ``add1``/``add2`` are further
+    gradients reaching x, added into dx."""
+    _dev(x1, x2, dy, coef, stat1, stat2, gamma, beta, add1, add2)
+    B, H, W_, C1 = x1.shape
+    C2 = 0 if x2 is None else x2.shape[3]
+    C = C1 + C2
+    code = _dtype_code(x1)
+    nsg = gn_nsplit(H * W_)
+    gsum = torch.empty((B, nsg, C, 2), dtype=torch.float32, device=x1.device)
+    check(lib.mad_gn_bwd_partial(_ptr(x1), C1, _ptr(x2), C2, _ptr(dy), dy_mode, _ptr(coef), int(act), code, _ptr(gsum),
+                                 B, H, W_, nsg, _stream()), "mad_gn_bwd_partial")
+    bcoef = torch.empty((B, C, 4), dtype=torch.float32, device=x1.device)
+    dgb = torch.empty((B, 2 * C), dtype=torch.float32, device=x1.device)
+    ns1 = stat1.shape[1]
+    ns2 = 0 if stat2 is None else stat2.shape[1]
+    check(lib.mad_gn_bwd_finalize(_ptr(stat1), C1, ns1, _ptr(stat2), C2, ns2, _ptr(gsum), nsg, _ptr(gamma), _ptr(beta),
+                                  None if ada is None else ada.data_ptr(), ada_stride, _ptr(bcoef), _ptr(dgb),
+                                  None if dada is None else dada.data_ptr(), B, groups, H * W_, float(eps), _stream()),
+          "mad_gn_bwd_finalize")
+    dg = bias_grad(dgb)
+    dx1 = dx2 = None
+    if need_dx:
+        dx1 = torch.empty_like(x1)
+        dx2 = None if x2 is None else torch.empty_like(x2)
+        check(lib.mad_gn_bwd_apply(_ptr(x1), C1, _ptr(x2), C2, _ptr(dy), dy_mode, _ptr(coef), int(act), _ptr(bcoef),
+                                   _ptr(add1), add1_mode, _ptr(add2), add2_mode, _ptr(dx1), _ptr(dx2), code, B, H, W_,
+                                   _stream()), "mad_gn_bwd_apply")
+    return dx1, dx2, dg[:C], dg[C:]
+
+
 # ------------------------------------------------------------------------------ GroupNorm
 def gn_nsplit(HW: int) -> int:
     return min(64, max(1, HW // 64))

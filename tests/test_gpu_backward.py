@@ -59,3 +59,68 @@ def test_conv_wgrad(dev, case, dt):
     assert rel_err(base.cpu() - 0.5, w0.grad) < 1e-4
     db = ops.bias_grad(_nhwc(dy, dt, dev))
     assert rel_err(db.cpu(), q(dy).double().sum((0, 2, 3))) < 2e-5
+
+
+GN_CASES = [
+    # B, H, C1, C2, groups, act, ada, dy_mode, adds
+    (2, 16, 64, 0, 32, True, True, 0, ()),
+    (3, 8, 32, 32, 32, True, False, 0, (0,)),           # two sources, one added gradient
+    (2, 16, 64, 0, 32, True, True, 1, (1,)),            # h was 2x2-averaged afterwards; residual at half resolution
+    (2, 8, 48, 0, 16, True, False, 2, (2, 0)),          # h was upsampled afterwards; two added gradients
+    (2, 32, 320, 0, 32, False, False, 0, ()),           # no activation (the attention block's norm)
+]
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", GN_CASES)
+def test_gn_backward(dev, case, dt):
+    from mad_amd import ops
+    B, H, C1, C2, groups, act, use_ada, dy_mode, adds = case
+    C = C1 + C2
+    q = (lambda t: t.to(dt).float()) if dt == torch.bfloat16 else (lambda t: t)
+    x = q(_rand((B, C, H, H), 1, 1.3) + 0.2)
+    gamma, beta = 1 + 0.2 * _rand((C,), 2), 0.2 * _rand((C,), 3)
+    ada = 0.3 * _rand((B, 2 * C + 5), 4) if use_ada else None         # row stride wider than 2C
+    Hd = {0: H, 1: H // 2, 2: 2 * H}[dy_mode]
+    dy = q(_rand((B, C, Hd, Hd), 5))
+    add_ts = [q(_rand((B, C, {0: H, 1: H // 2, 2: 2 * H}[m], {0: H, 1: H // 2, 2: 2 * H}[m]), 6 + i))
+              for i, m in enumerate(adds)]
+
+    # reference in fp64 through autograd
+    xr = x.double().requires_grad_(True)
+    gr, br = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    ar = None if ada is None else ada.double().requires_grad_(True)
+    n = F.group_norm(xr, groups, gr, br, eps=1e-5)
+    if ar is not None:
+        n = ar[:, C:2 * C, None, None] + n * (ar[:, :C, None, None] + 1)
+    hh = F.silu(n) if act else n
+    if dy_mode == 1:
+        hh = F.avg_pool2d(hh, 2)
+    elif dy_mode == 2:
+        hh = F.interpolate(hh, scale_factor=2, mode="nearest")
+    loss = (hh * dy.double()).sum()
+    for t, m in zip(add_ts, adds):
+        br_ = xr if m == 0 else (F.avg_pool2d(xr, 2) if m == 1 else F.interpolate(xr, scale_factor=2, mode="nearest"))
+        loss = loss + (br_ * t.double()).sum()
+    loss.backward()
+
+    xn = _nhwc(x, dt, dev)
+    x1, x2 = xn[..., :C1].contiguous(), (xn[..., C1:].contiguous() if C2 else None)
+    ada_d = None if ada is None else ada.to(dev)
+    stride = 0 if ada is None else ada.shape[1]
+    st1, st2 = ops.gn_partial(x1), (None if x2 is None else ops.gn_partial(x2))
+    coef = ops.gn_finalize(st1, H * H, gamma.to(dev), beta.to(dev), groups, 1e-5, ada=ada_d, ada_stride=stride,
+                           partial2=st2)
+    dada = None if ada is None else torch.zeros_like(ada_d)
+    a = [(_nhwc(t, dt, dev), m) for t, m in zip(add_ts, adds)] + [(None, 0), (None, 0)]
+    dx1, dx2, dg, db = ops.gn_backward(x1, _nhwc(dy, dt, dev), coef, st1, gamma.to(dev), beta.to(dev), groups, 1e-5, act,
+                                       x2=x2, stat2=st2, ada=ada_d, ada_stride=stride, dada=dada, dy_mode=dy_mode,
+                                       add1=a[0][0], add1_mode=a[0][1], add2=a[1][0], add2_mode=a[1][1])
+    dx = dx1 if dx2 is None else torch.cat([dx1, dx2], -1)
+    tol = 2e-5 if dt == torch.float32 else 8e-3
+    assert rel_err(dx.float().permute(0, 3, 1, 2).cpu(), xr.grad) < tol
+    assert rel_err(dg.cpu(), gr.grad) < 1e-4
+    assert rel_err(db.cpu(), br.grad) < 1e-4
+    if ada is not None:
+        assert rel_err(dada[:, :2 * C].cpu(), ar.grad[:, :2 * C]) < 1e-4
+        assert float(dada[:, 2 * C:].abs().max()) == 0.0
