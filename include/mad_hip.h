@@ -264,6 +264,18 @@ int mad_gn_bwd_apply(const void* x1, int C1, const void* x2, int C2, const void*
                      const void* add2, int add2_mode, void* dx1, void* dx2, int dtype, int B, int H,
                      int W, void* stream);
 
+/* mad_attention that also writes lse (B, heads, L) fp32: the log-sum-exp of each query's scaled scores,
+ * which the backward needs. */
+int mad_attention_lse(const void* qkv, void* out, float* lse, int dtype, int B, int L, int heads,
+                      void* stream);
+
+/* Backward of mad_attention (bf16 only): qkv, out and lse as the forward took / wrote them, dout (B,L,C)
+ * the gradient of out; writes dqkv (B,L,3C) in the layout of qkv and uses dsum (B, heads, L) fp32 as
+ * scratch (dout . out per query).  The probabilities are rebuilt tile by tile from lse.
+ * Autograd of the attention of model.py:357-375 / AttentionOp.backward (model.py:214-229). */
+int mad_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* dsum,
+                      void* dqkv, int dtype, int B, int L, int heads, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

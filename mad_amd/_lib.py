@@ -69,6 +69,8 @@ SIGNATURES = {
                                 c_void_p, c_int, c_int, c_int, c_float, c_void_p]),
     "mad_gn_apply": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
     "mad_attention": (c_int, [c_void_p, c_void_p] + [c_int] * 4 + [c_void_p]),
+    "mad_attention_lse": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 4 + [c_void_p]),
+    "mad_attention_bwd": (c_int, [c_void_p] * 6 + [c_int] * 4 + [c_void_p]),
 }
 
 

@@ -18,8 +18,8 @@ template <> struct AttnLds<bf16_t> { static constexpr int ROW = 128; };
 template <> struct AttnLds<float> { static constexpr int ROW = 256; };
 
 template <typename T, int NW>
-__global__ __launch_bounds__(NW * 64) void attention_kernel(const T* __restrict__ qkv, T* __restrict__ out, int L,
-                                                             int heads) {
+__global__ __launch_bounds__(NW * 64) void attention_kernel(const T* __restrict__ qkv, T* __restrict__ out,
+                                                             float* __restrict__ lse, int L, int heads) {
     constexpr int VEC = Elem<T>::VEC;
     constexpr int ROW = AttnLds<T>::ROW;          // bytes per key row in LDS
     constexpr int CHUNKS = ROW / 16;              // 16-byte chunks per row
@@ -163,6 +163,8 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(const T* __restrict_
     const float l = l_run + __shfl_xor(l_run, 32);
     const float inv = 1.0f / l;
     const int C = heads * HD;
+    // log-sum-exp of the query's scaled scores: what the backward needs to rebuild the probabilities
+    if (lse && fh == 0) lse[((size_t)b * heads + head) * L + q0 + qi] = m_run + __logf(l);
     T* orow = out + ((size_t)b * L + q0 + qi) * C + head * HD;
 #pragma unroll
     for (int dh = 0; dh < 2; ++dh)
@@ -188,23 +190,34 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(const T* __restrict_
 
 using namespace mad;
 
-extern "C" int mad_attention(const void* qkv, void* out, int dtype, int B, int L, int heads, void* stream) {
-    MAD_REQUIRE(qkv && out, "mad_attention: null pointer");
-    MAD_REQUIRE(dtype == MAD_BF16 || dtype == MAD_F32, "mad_attention: bad dtype %d", dtype);
-    MAD_REQUIRE(B > 0 && heads > 0 && L >= 64 && L % 64 == 0, "mad_attention: L=%d must be a multiple of 64", L);
+static int attention_impl(const void* qkv, void* out, float* lse, int dtype, int B, int L, int heads, void* stream,
+                          const char* who) {
+    MAD_REQUIRE(qkv && out, "%s: null pointer", who);
+    MAD_REQUIRE(dtype == MAD_BF16 || dtype == MAD_F32, "%s: bad dtype %d", who, dtype);
+    MAD_REQUIRE(B > 0 && heads > 0 && L >= 64 && L % 64 == 0, "%s: L=%d must be a multiple of 64", who, L);
     hipStream_t s = (hipStream_t)stream;
     if (L % 128 == 0) {
         dim3 grid(L / 128, heads, B);
         if (dtype == MAD_BF16)
-            hipLaunchKernelGGL((attention_kernel<bf16_t, 4>), grid, dim3(256), 0, s, (const bf16_t*)qkv, (bf16_t*)out, L, heads);
+            hipLaunchKernelGGL((attention_kernel<bf16_t, 4>), grid, dim3(256), 0, s, (const bf16_t*)qkv, (bf16_t*)out, lse, L, heads);
         else
-            hipLaunchKernelGGL((attention_kernel<float, 4>), grid, dim3(256), 0, s, (const float*)qkv, (float*)out, L, heads);
+            hipLaunchKernelGGL((attention_kernel<float, 4>), grid, dim3(256), 0, s, (const float*)qkv, (float*)out, lse, L, heads);
     } else {
         dim3 grid(L / 64, heads, B);
         if (dtype == MAD_BF16)
-            hipLaunchKernelGGL((attention_kernel<bf16_t, 2>), grid, dim3(128), 0, s, (const bf16_t*)qkv, (bf16_t*)out, L, heads);
+            hipLaunchKernelGGL((attention_kernel<bf16_t, 2>), grid, dim3(128), 0, s, (const bf16_t*)qkv, (bf16_t*)out, lse, L, heads);
         else
-            hipLaunchKernelGGL((attention_kernel<float, 2>), grid, dim3(128), 0, s, (const float*)qkv, (float*)out, L, heads);
+            hipLaunchKernelGGL((attention_kernel<float, 2>), grid, dim3(128), 0, s, (const float*)qkv, (float*)out, lse, L, heads);
     }
-    return check_launch("mad_attention");
+    return check_launch(who);
+}
+
+extern "C" int mad_attention(const void* qkv, void* out, int dtype, int B, int L, int heads, void* stream) {
+    return attention_impl(qkv, out, nullptr, dtype, B, L, heads, stream, "mad_attention");
+}
+
+extern "C" int mad_attention_lse(const void* qkv, void* out, float* lse, int dtype, int B, int L, int heads,
+                                 void* stream) {
+    MAD_REQUIRE(lse, "mad_attention_lse: null pointer");
+    return attention_impl(qkv, out, lse, dtype, B, L, heads, stream, "mad_attention_lse");
 }

@@ -513,8 +513,9 @@ def gn_apply(x1: Tensor, coef: Tensor, act: bool, x2: Optional[Tensor] = None, p
 
 
 # ------------------------------------------------------------------------------ attention
-def attention(qkv: Tensor, heads: int) -> Tensor:
-    """qkv (B,H,W,3C) with per-head [q|k|v] channel blocks -> (B,H,W,C)."""
+def attention(qkv: Tensor, heads: int, want_lse: bool = False):
+    """qkv (B,H,W,3C) with per-head [q|k|v] channel blocks -> (B,H,W,C); with ``want_lse`` also the
+    per-query log-sum-exp (B, heads, H*W) that ``attention_backward`` needs."""
     _dev(qkv)
     B, H, W_, C3 = qkv.shape
     C = C3 // 3
@@ -522,7 +523,28 @@ def attention(qkv: Tensor, heads: int) -> Tensor:
         raise ValueError(f"attention needs head_dim 64: C={C}, heads={heads}")
     out = torch.empty((B, H, W_, C), dtype=qkv.dtype, device=qkv.device)
     end = TIMER.bracket("attention", 4.0 * B * (H * W_) ** 2 * C)
-    check(lib.mad_attention(_ptr(qkv), _ptr(out), _dtype_code(qkv), B, H * W_, heads, _stream()), "mad_attention")
+    if want_lse:
+        lse = torch.empty((B, heads, H * W_), dtype=torch.float32, device=qkv.device)
+        check(lib.mad_attention_lse(_ptr(qkv), _ptr(out), _ptr(lse), _dtype_code(qkv), B, H * W_, heads, _stream()),
+              "mad_attention_lse")
+    else:
+        check(lib.mad_attention(_ptr(qkv), _ptr(out), _dtype_code(qkv), B, H * W_, heads, _stream()), "mad_attention")
     if end is not None:
         end.record()
-    return out
+    return (out, lse) if want_lse else out
+
+
+def attention_backward(qkv: Tensor, out: Tensor, dout: Tensor, lse: Tensor, heads: int) -> Tensor:
+    """Gradient of ``attention`` w.r.t. qkv (same layout), bf16 only."""
+    _dev(qkv, out, dout, lse)
+    B, H, W_, C3 = qkv.shape
+    if out.shape != dout.shape or out.dtype != qkv.dtype or dout.dtype != qkv.dtype or not dout.is_contiguous():
+        raise ValueError("attention_backward: out / dout must be contiguous tensors of the forward's output shape")
+    dqkv = torch.empty_like(qkv)
+    dsum = torch.empty_like(lse)
+    end = TIMER.bracket("attention_bwd", 10.0 * B * (H * W_) ** 2 * (C3 // 3))
+    check(lib.mad_attention_bwd(_ptr(qkv), _ptr(out), _ptr(dout), _ptr(lse), _ptr(dsum), _ptr(dqkv), _dtype_code(qkv),
+                                B, H * W_, heads, _stream()), "mad_attention_bwd")
+    if end is not None:
+        end.record()
+    return dqkv

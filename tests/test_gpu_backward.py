@@ -10,6 +10,13 @@ from conftest import rel_err
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _grad_on():
+    """The references here are autograd graphs; other test modules may have switched autograd off."""
+    with torch.enable_grad():
+        yield
+
+
 @pytest.fixture(scope="module")
 def dev():
     return torch.device("cuda:0")
@@ -124,3 +131,28 @@ def test_gn_backward(dev, case, dt):
     if ada is not None:
         assert rel_err(dada[:, :2 * C].cpu(), ar.grad[:, :2 * C]) < 1e-4
         assert float(dada[:, 2 * C:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("case", [(2, 8, 2), (1, 16, 3), (2, 32, 1)])
+def test_attention_backward(dev, case):
+    """dQ, dK, dV of the flash-style backward against autograd through an fp64 softmax attention."""
+    from mad_amd import ops
+    B, R, heads = case
+    L, C = R * R, heads * 64
+    dt = torch.bfloat16
+    qkv = _rand((B, L, heads, 3, 64), 1, 1.0).to(dt)
+    dout = _rand((B, L, heads, 64), 2).to(dt)
+    ref = qkv.double().requires_grad_(True)
+    q, k, v = ref[:, :, :, 0], ref[:, :, :, 1], ref[:, :, :, 2]                  # (B, L, heads, 64)
+    w = torch.einsum("bqhd,bkhd->bhqk", q, k) / 8.0
+    o = torch.einsum("bhqk,bkhd->bqhd", w.softmax(-1), v)
+    (o * dout.double()).sum().backward()
+    qkv_d = qkv.reshape(B, R, R, 3 * C).to(dev)
+    out, lse = ops.attention(qkv_d, heads, want_lse=True)
+    assert rel_err(out.float().cpu().reshape(B, L, heads, 64), o.detach()) < 8e-3
+    want_lse = torch.logsumexp(w.detach(), -1)                                    # (B, heads, L)
+    assert float((lse.cpu().double() - want_lse).abs().max()) < 2e-2
+    dqkv = ops.attention_backward(qkv_d, out, dout.reshape(B, R, R, C).to(dev), lse, heads)
+    got = dqkv.float().cpu().reshape(B, L, heads, 3, 64)
+    for i, name in enumerate("qkv"):
+        assert rel_err(got[:, :, :, i], ref.grad[:, :, :, i]) < 1.5e-2, name
