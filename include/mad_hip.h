@@ -269,12 +269,47 @@ int mad_gn_bwd_apply(const void* x1, int C1, const void* x2, int C2, const void*
 int mad_attention_lse(const void* qkv, void* out, float* lse, int dtype, int B, int L, int heads,
                       void* stream);
 
-/* Backward of mad_attention (bf16 only): qkv, out and lse as the forward took / wrote them, dout (B,L,C)
+/* Backward of mad_attention (bf16 on MFMA; fp32 on a simple one-wave-per-row kernel): qkv, out and lse as the forward took / wrote them, dout (B,L,C)
  * the gradient of out; writes dqkv (B,L,3C) in the layout of qkv and uses dsum (B, heads, L) fp32 as
  * scratch (dout . out per query).  The probabilities are rebuilt tile by tile from lse.
  * Autograd of the attention of model.py:357-375 / AttentionOp.backward (model.py:214-229). */
 int mad_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* dsum,
                       void* dqkv, int dtype, int B, int L, int heads, void* stream);
+
+/* mad_conv_wgrad for the first and last layer, whose image-side operand is NCHW fp32: each operand
+ * has its own dtype (MAD_BF16 / MAD_F32) and layout flag (1 = NCHW, 0 = NHWC).  Generic vector-ALU
+ * kernel.  Autograd of enc.{R}x{R}_conv and out_conv (model.py:506-508, 549-551) w.r.t. `weight`. */
+size_t mad_conv_wgrad_edge_workspace(int B, int H, int W, int Cin, int Cout, int ksize);
+int mad_conv_wgrad_edge(const void* x, int x_dtype, int x_nchw, const void* dy, int dy_dtype, int dy_nchw,
+                        float* dw, void* workspace, size_t workspace_bytes, int B, int H, int W, int Cin,
+                        int Cout, int ksize, int accumulate, void* stream);
+
+/* Backward of mad_linear_f32 (y = act_in(xpre) @ W^T + bias), fp32:
+ *   input : dx[r,k] (+)= (sum_n dy[r,n]*W[n,k]) * (act_in ? silu'(xpre[r,k]) : 1)   (xpre may be NULL without act_in)
+ *   weight: dW[n,k]   = sum_r dy[r,n] * act_in(xpre[r,k])        (bias: mad_bias_grad over dy)
+ * Autograd of Linear.forward (model.py:60-64). */
+int mad_linear_bwd_input(const float* dy, const float* W, const float* xpre, float* dx, int rows, int K,
+                         int N, int act_in, int accumulate, void* stream);
+int mad_linear_bwd_weight(const float* dy, const float* xpre, float* dW, int rows, int K, int N,
+                          int act_in, void* stream);
+
+/* y[i] = keep(seed, i) ? x[i]/(1-p) : 0 with a counter-based keep decision, so the backward applies the
+ * same mask to the gradient by calling it again with the same seed (in place allowed).
+ * F.dropout in UNetBlock.forward (model.py:350-352); the random stream differs from torch's. */
+int mad_dropout(const void* x, void* y, int dtype, size_t n, unsigned long long seed, float p,
+                void* stream);
+
+/* grad = 2*(pred-target)/n and partial[j] = the j-th workgroup's sum of (pred-target)^2 (loss =
+ * sum(partial)/n), fp32.  F.mse_loss and its gradient (main.py:243). */
+int mad_mse_loss_grad(const float* pred, const float* target, float* grad, float* partial, int npartial,
+                      size_t n, void* stream);
+
+/* One fused pass over flat fp32 buffers: g = nan_to_num(grad*grad_scale, 0, 1e5, -1e5) (main.py:249-251);
+ * AdamW with decoupled weight decay as torch.optim.AdamW at 1-based `step` (main.py:173-178, 252);
+ * ema -= (1-ema_decay)*(ema-param) when ema is not NULL (EMAModel.step, main.py:256-257). */
+int mad_adamw_step(float* param, const float* grad, float* m, float* v, float* ema, size_t n, float lr,
+                   float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
+                   float ema_decay, void* stream);
 
 #ifdef __cplusplus
 }

@@ -259,6 +259,60 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const bf16_t* __r
     store_rows(orow + 2 * HD, dv, 1.0f, fh);
 }
 
+// ------------------------------------------------------------------------------------------- fp32 mode
+// One wave per query (dQ, D) or per key (dK, dV), lane = head-dim index, dot products by wave reduction.
+// The fp32 mode is the tight-tolerance check of the training step, not a throughput path.
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+__global__ __launch_bounds__(64) void attn_bwd_dq_f32_kernel(const float* __restrict__ qkv, const float* __restrict__ out,
+                                                              const float* __restrict__ dout, const float* __restrict__ lse,
+                                                              float* __restrict__ dsum, float* __restrict__ dqkv, int L,
+                                                              int heads) {
+    const int q = blockIdx.x, head = blockIdx.y, b = blockIdx.z, d = threadIdx.x;
+    const int C3 = heads * 192, C = heads * 64;
+    const float* base = qkv + (size_t)b * L * C3 + head * 192;
+    const float qd = base[(size_t)q * C3 + d] * 0.125f;
+    const float dod = dout[((size_t)b * L + q) * C + head * 64 + d];
+    const float D = wave_sum(dod * out[((size_t)b * L + q) * C + head * 64 + d]);
+    const size_t srow = ((size_t)b * heads + head) * L + q;
+    if (d == 0) dsum[srow] = D;
+    const float l = lse[srow];
+    float acc = 0.0f;
+    for (int k = 0; k < L; ++k) {
+        const float kd = base[(size_t)k * C3 + 64 + d], vd = base[(size_t)k * C3 + 128 + d];
+        const float s = wave_sum(qd * kd), dp = wave_sum(dod * vd);
+        acc = fmaf(__expf(s - l) * (dp - D), kd, acc);
+    }
+    dqkv[((size_t)b * L + q) * C3 + head * 192 + d] = acc * 0.125f;
+}
+
+__global__ __launch_bounds__(64) void attn_bwd_dkv_f32_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
+                                                               const float* __restrict__ lse, const float* __restrict__ dsum,
+                                                               float* __restrict__ dqkv, int L, int heads) {
+    const int k = blockIdx.x, head = blockIdx.y, b = blockIdx.z, d = threadIdx.x;
+    const int C3 = heads * 192, C = heads * 64;
+    const float* base = qkv + (size_t)b * L * C3 + head * 192;
+    const float kd = base[(size_t)k * C3 + 64 + d], vd = base[(size_t)k * C3 + 128 + d];
+    const float* lrow = lse + ((size_t)b * heads + head) * L;
+    const float* srow = dsum + ((size_t)b * heads + head) * L;
+    float dk = 0.0f, dv = 0.0f;
+    for (int q = 0; q < L; ++q) {
+        const float qd = base[(size_t)q * C3 + d] * 0.125f;
+        const float dod = dout[((size_t)b * L + q) * C + head * 64 + d];
+        const float p = __expf(wave_sum(qd * kd) - lrow[q]);
+        const float ds = p * (wave_sum(dod * vd) - srow[q]);
+        dv = fmaf(p, dod, dv);
+        dk = fmaf(ds, qd, dk);
+    }
+    float* orow = dqkv + ((size_t)b * L + k) * C3 + head * 192;
+    orow[64 + d] = dk;
+    orow[128 + d] = dv;
+}
+
 }  // namespace mad
 
 using namespace mad;
@@ -266,9 +320,18 @@ using namespace mad;
 extern "C" int mad_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* dsum,
                                  void* dqkv, int dtype, int B, int L, int heads, void* stream) {
     MAD_REQUIRE(qkv && out && dout && lse && dsum && dqkv, "mad_attention_bwd: null pointer");
-    MAD_REQUIRE(dtype == MAD_BF16, "mad_attention_bwd: bf16 only (dtype %d)", dtype);
+    MAD_REQUIRE(dtype == MAD_BF16 || dtype == MAD_F32, "mad_attention_bwd: bad dtype %d", dtype);
     MAD_REQUIRE(B > 0 && heads > 0 && L >= 64 && L % 64 == 0, "mad_attention_bwd: L=%d must be a multiple of 64", L);
     hipStream_t s = (hipStream_t)stream;
+    if (dtype == MAD_F32) {
+        const dim3 grid(L, heads, B);
+        hipLaunchKernelGGL(attn_bwd_dq_f32_kernel, grid, dim3(64), 0, s, (const float*)qkv, (const float*)out,
+                           (const float*)dout, lse, dsum, (float*)dqkv, L, heads);
+        if (int rc = check_launch("mad_attention_bwd (dq)")) return rc;
+        hipLaunchKernelGGL(attn_bwd_dkv_f32_kernel, grid, dim3(64), 0, s, (const float*)qkv, (const float*)dout, lse,
+                           (const float*)dsum, (float*)dqkv, L, heads);
+        return check_launch("mad_attention_bwd (dkv)");
+    }
     const bf16_t* q = (const bf16_t*)qkv; const bf16_t* o = (const bf16_t*)out; const bf16_t* d = (const bf16_t*)dout;
     bf16_t* g = (bf16_t*)dqkv;
     if (L % 128 == 0) {

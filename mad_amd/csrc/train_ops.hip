@@ -1,0 +1,186 @@
+// Small kernels of the training step: backward of the fp32 linear layers (embedding MLP, per-block
+// affines), dropout with a counter-based mask, the mean-squared-error loss and its gradient, and the
+// fused parameter update (gradient clean-up, AdamW, EMA).  All HBM-bound or tiny.
+#include "common.h"
+
+namespace mad {
+
+__device__ __forceinline__ float silu_grad_t(float u) {
+    const float s = 1.0f / (1.0f + __expf(-u));
+    return s * fmaf(u, 1.0f - s, 1.0f);
+}
+
+// dX[r,k] = (sum_n dY[r,n] * W[n,k]) * (act_in ? silu'(xpre[r,k]) : 1); grid (ceil(K/256), rows)
+__global__ __launch_bounds__(256) void linear_dx_kernel(const float* __restrict__ dy, const float* __restrict__ w,
+                                                         const float* __restrict__ xpre, float* __restrict__ dx, int N,
+                                                         int K, int act_in, int accumulate) {
+    const int k = blockIdx.x * 256 + threadIdx.x, r = blockIdx.y;
+    if (k >= K) return;
+    const float* g = dy + (size_t)r * N;
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+    int n = 0;
+    for (; n + 4 <= N; n += 4) {
+        s0 = fmaf(g[n], w[(size_t)n * K + k], s0);
+        s1 = fmaf(g[n + 1], w[(size_t)(n + 1) * K + k], s1);
+        s2 = fmaf(g[n + 2], w[(size_t)(n + 2) * K + k], s2);
+        s3 = fmaf(g[n + 3], w[(size_t)(n + 3) * K + k], s3);
+    }
+    for (; n < N; ++n) s0 = fmaf(g[n], w[(size_t)n * K + k], s0);
+    float s = (s0 + s1) + (s2 + s3);
+    if (act_in) s *= silu_grad_t(xpre[(size_t)r * K + k]);
+    float* o = dx + (size_t)r * K + k;
+    *o = accumulate ? *o + s : s;
+}
+
+// dW[n,k] = sum_r dY[r,n] * (act_in ? silu(xpre[r,k]) : xpre[r,k]); grid (ceil(K/256), N)
+__global__ __launch_bounds__(256) void linear_dw_kernel(const float* __restrict__ dy, const float* __restrict__ xpre,
+                                                         float* __restrict__ dw, int rows, int N, int K, int act_in) {
+    const int k = blockIdx.x * 256 + threadIdx.x, n = blockIdx.y;
+    if (k >= K) return;
+    float s = 0.0f;
+    for (int r = 0; r < rows; ++r) {
+        const float x = xpre[(size_t)r * K + k];
+        s = fmaf(dy[(size_t)r * N + n], act_in ? silu_f(x) : x, s);
+    }
+    dw[(size_t)n * K + k] = s;
+}
+
+// keep-mask from a counter hash: element i of call `seed` is kept with probability 1-p and scaled by 1/(1-p)
+__device__ __forceinline__ unsigned mix32(unsigned x) {
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void dropout_kernel(const T* __restrict__ x, T* __restrict__ y, size_t nvec,
+                                                       unsigned long long seed, float p, float scale) {
+    constexpr int VEC = Elem<T>::VEC;
+    const unsigned thr = (unsigned)(p * 4294967296.0);
+    const unsigned s0 = mix32((unsigned)seed), s1 = mix32((unsigned)(seed >> 32) ^ 0x9e3779b9u);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (size_t)gridDim.x * 256) {
+        Vec16<T> v; v.load(x + i * VEC);
+        float f[VEC]; v.unpack(f);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            const unsigned long long e = i * VEC + j;
+            const unsigned h = mix32(mix32((unsigned)e ^ s0) + (unsigned)(e >> 32) + s1);
+            f[j] = h >= thr ? f[j] * scale : 0.0f;
+        }
+        v.pack(f);
+        v.store(y + i * VEC);
+    }
+}
+
+// grad = 2*(pred - target)/n; partial[block] = sum of squared differences of the block's elements
+__global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ pred, const float* __restrict__ target,
+                                                   float* __restrict__ grad, float* __restrict__ partial, size_t n,
+                                                   float gscale) {
+    __shared__ float red[256];
+    float s = 0.0f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float d = pred[i] - target[i];
+        grad[i] = d * gscale;
+        s = fmaf(d, d, s);
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
+struct AdamArgs {
+    float* param; const float* grad; float* m; float* v; float* ema;
+    size_t n;
+    float lr, beta1, beta2, eps, weight_decay, bias1, bias2_sqrt, grad_scale, ema_decay;
+};
+
+// torch.nan_to_num(grad, 0, 1e5, -1e5) (main.py:249-251), AdamW with decoupled weight decay
+// (torch.optim.AdamW: main.py:173-178), then the EMA shadow update (main.py:256-257)
+__global__ __launch_bounds__(256) void adamw_kernel(AdamArgs a) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (size_t)gridDim.x * 256) {
+        float g = a.grad[i] * a.grad_scale;
+        if (g != g) g = 0.0f;
+        else if (g > 3.0e38f) g = 1.0e5f;
+        else if (g < -3.0e38f) g = -1.0e5f;
+        float p = a.param[i];
+        p *= 1.0f - a.lr * a.weight_decay;
+        const float m = a.beta1 * a.m[i] + (1.0f - a.beta1) * g;
+        const float v = a.beta2 * a.v[i] + (1.0f - a.beta2) * g * g;
+        a.m[i] = m; a.v[i] = v;
+        const float denom = sqrtf(v) / a.bias2_sqrt + a.eps;
+        p -= (a.lr / a.bias1) * (m / denom);
+        a.param[i] = p;
+        if (a.ema) { const float e = a.ema[i]; a.ema[i] = e - (1.0f - a.ema_decay) * (e - p); }
+    }
+}
+
+}  // namespace mad
+
+using namespace mad;
+
+extern "C" int mad_linear_bwd_input(const float* dy, const float* W, const float* xpre, float* dx, int rows, int K,
+                                    int N, int act_in, int accumulate, void* stream) {
+    MAD_REQUIRE(dy && W && dx && (!act_in || xpre), "mad_linear_bwd_input: null pointer");
+    MAD_REQUIRE(rows > 0 && K > 0 && N > 0, "mad_linear_bwd_input: bad shape");
+    hipLaunchKernelGGL(linear_dx_kernel, dim3((K + 255) / 256, rows), dim3(256), 0, (hipStream_t)stream, dy, W, xpre, dx,
+                       N, K, act_in, accumulate);
+    return check_launch("mad_linear_bwd_input");
+}
+
+extern "C" int mad_linear_bwd_weight(const float* dy, const float* xpre, float* dW, int rows, int K, int N, int act_in,
+                                     void* stream) {
+    MAD_REQUIRE(dy && xpre && dW, "mad_linear_bwd_weight: null pointer");
+    MAD_REQUIRE(rows > 0 && K > 0 && N > 0, "mad_linear_bwd_weight: bad shape");
+    hipLaunchKernelGGL(linear_dw_kernel, dim3((K + 255) / 256, N), dim3(256), 0, (hipStream_t)stream, dy, xpre, dW, rows,
+                       N, K, act_in);
+    return check_launch("mad_linear_bwd_weight");
+}
+
+extern "C" int mad_dropout(const void* x, void* y, int dtype, size_t n, unsigned long long seed, float p, void* stream) {
+    MAD_REQUIRE(x && y, "mad_dropout: null pointer");
+    MAD_REQUIRE(dtype == MAD_BF16 || dtype == MAD_F32, "mad_dropout: bad dtype %d", dtype);
+    MAD_REQUIRE(p >= 0.0f && p < 1.0f, "mad_dropout: p=%f out of [0,1)", (double)p);
+    const int VEC = dtype == MAD_BF16 ? 8 : 4;
+    MAD_REQUIRE(n % VEC == 0, "mad_dropout: element count must be a multiple of %d", VEC);
+    const size_t nvec = n / VEC;
+    if (nvec == 0) return 0;
+    size_t g = (nvec + 255) / 256;
+    if (g > 8192) g = 8192;
+    const float scale = 1.0f / (1.0f - p);
+    if (dtype == MAD_BF16)
+        hipLaunchKernelGGL(dropout_kernel<bf16_t>, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
+                           (bf16_t*)y, nvec, seed, p, scale);
+    else
+        hipLaunchKernelGGL(dropout_kernel<float>, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, (const float*)x,
+                           (float*)y, nvec, seed, p, scale);
+    return check_launch("mad_dropout");
+}
+
+extern "C" int mad_mse_loss_grad(const float* pred, const float* target, float* grad, float* partial, int npartial,
+                                 size_t n, void* stream) {
+    MAD_REQUIRE(pred && target && grad && partial, "mad_mse_loss_grad: null pointer");
+    MAD_REQUIRE(n > 0 && npartial > 0 && npartial <= 4096, "mad_mse_loss_grad: bad sizes");
+    hipLaunchKernelGGL(mse_kernel, dim3(npartial), dim3(256), 0, (hipStream_t)stream, pred, target, grad, partial, n,
+                       2.0f / (float)n);
+    return check_launch("mad_mse_loss_grad");
+}
+
+extern "C" int mad_adamw_step(float* param, const float* grad, float* m, float* v, float* ema, size_t n, float lr,
+                              float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
+                              float ema_decay, void* stream) {
+    MAD_REQUIRE(param && grad && m && v, "mad_adamw_step: null pointer");
+    MAD_REQUIRE(step >= 1, "mad_adamw_step: step counts from 1");
+    if (n == 0) return 0;
+    AdamArgs a;
+    a.param = param; a.grad = grad; a.m = m; a.v = v; a.ema = ema; a.n = n; a.lr = lr; a.beta1 = beta1; a.beta2 = beta2;
+    a.eps = eps; a.weight_decay = weight_decay; a.grad_scale = grad_scale; a.ema_decay = ema_decay;
+    a.bias1 = (float)(1.0 - pow((double)beta1, step));
+    a.bias2_sqrt = (float)sqrt(1.0 - pow((double)beta2, step));
+    size_t g = (n + 255) / 256;
+    if (g > 8192) g = 8192;
+    hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, a);
+    return check_launch("mad_adamw_step");
+}

@@ -294,3 +294,40 @@ extern "C" int mad_bias_grad(const void* dy, int dtype, long rows, int C, float*
                        (size_t)C, splits, accumulate, 0, 1);
     return check_launch("mad_bias_grad (reduce)");
 }
+
+// First / last layer: operands in different dtypes and layouts (the image side is NCHW fp32).
+extern "C" size_t mad_conv_wgrad_edge_workspace(int B, int H, int W, int Cin, int Cout, int ksize) {
+    return mad_conv_wgrad_workspace(MAD_F32, B, H, W, Cin, Cout, ksize);      // MAD_F32 always takes the generic split
+}
+
+extern "C" int mad_conv_wgrad_edge(const void* x, int x_dtype, int x_nchw, const void* dy, int dy_dtype, int dy_nchw,
+                                   float* dw, void* workspace, size_t workspace_bytes, int B, int H, int W, int Cin,
+                                   int Cout, int ksize, int accumulate, void* stream) {
+    MAD_REQUIRE(x && dy && dw && workspace, "mad_conv_wgrad_edge: null pointer");
+    MAD_REQUIRE((x_dtype == MAD_BF16 || x_dtype == MAD_F32) && (dy_dtype == MAD_BF16 || dy_dtype == MAD_F32),
+                "mad_conv_wgrad_edge: bad dtype");
+    MAD_REQUIRE(ksize == 1 || ksize == 3, "mad_conv_wgrad_edge: ksize %d not supported", ksize);
+    MAD_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "mad_conv_wgrad_edge: bad shape");
+    MAD_REQUIRE(workspace_bytes >= mad_conv_wgrad_edge_workspace(B, H, W, Cin, Cout, ksize),
+                "mad_conv_wgrad_edge: workspace of %zu bytes is too small", workspace_bytes);
+    hipStream_t s = (hipStream_t)stream;
+    const int nt = ksize * ksize;
+    const int ksplit = wgrad_ksplit(MAD_F32, B, H, W, Cin, Cout, ksize, nullptr);
+    WgradGenArgs a;
+    a.x = x; a.dy = dy; a.partial = (float*)workspace; a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
+    a.ks = ksize; a.ksplit = ksplit; a.upsample = 0;
+    if (x_nchw) { a.xsx = 1; a.xsy = W; a.xsc = (long)H * W; a.xsb = (long)Cin * H * W; }
+    else { a.xsc = 1; a.xsx = Cin; a.xsy = (long)W * Cin; a.xsb = (long)H * W * Cin; }
+    if (dy_nchw) { a.ysx = 1; a.ysy = W; a.ysc = (long)H * W; a.ysb = (long)Cout * H * W; }
+    else { a.ysc = 1; a.ysx = Cout; a.ysy = (long)W * Cout; a.ysb = (long)H * W * Cout; }
+    const dim3 grid(Cout * nt * ksplit);
+    if (x_dtype == MAD_F32 && dy_dtype == MAD_F32) hipLaunchKernelGGL((wgrad_generic_kernel<float, float>), grid, dim3(256), 0, s, a);
+    else if (x_dtype == MAD_F32) hipLaunchKernelGGL((wgrad_generic_kernel<float, bf16_t>), grid, dim3(256), 0, s, a);
+    else if (dy_dtype == MAD_F32) hipLaunchKernelGGL((wgrad_generic_kernel<bf16_t, float>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((wgrad_generic_kernel<bf16_t, bf16_t>), grid, dim3(256), 0, s, a);
+    if (int rc = check_launch("mad_conv_wgrad_edge")) return rc;
+    const size_t n = (size_t)Cout * nt * Cin;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const float*)workspace,
+                       dw, n, ksplit, accumulate, nt, Cin);
+    return check_launch("mad_conv_wgrad_edge (reduce)");
+}

@@ -416,6 +416,82 @@ def bias_grad(dy: Tensor, out: Optional[Tensor] = None, accumulate: bool = False
     return out
 
 
+def conv_wgrad_edge(x: Tensor, x_nchw: bool, dy: Tensor, dy_nchw: bool, ksize: int) -> Tensor:
+    """Weight gradient of the first / last conv: each operand NCHW or NHWC, bf16 or fp32; fp32 (Cout,Cin,k,k)."""
+    _dev(x, dy)
+    if x_nchw:
+        B, Cin, H, W_ = x.shape
+    else:
+        B, H, W_, Cin = x.shape
+    Cout = dy.shape[1] if dy_nchw else dy.shape[3]
+    want = (B, Cout, H, W_) if dy_nchw else (B, H, W_, Cout)
+    if tuple(dy.shape) != want or not x.is_contiguous() or not dy.is_contiguous():
+        raise ValueError(f"conv_wgrad_edge: dy {tuple(dy.shape)} does not fit x {tuple(x.shape)}")
+    out = torch.empty((Cout, Cin, ksize, ksize), dtype=torch.float32, device=x.device)
+    nbytes = lib.mad_conv_wgrad_edge_workspace(B, H, W_, Cin, Cout, ksize)
+    ws = torch.empty((nbytes,), dtype=torch.uint8, device=x.device)
+    check(lib.mad_conv_wgrad_edge(_ptr(x), _dtype_code(x), int(x_nchw), _ptr(dy), _dtype_code(dy), int(dy_nchw), _ptr(out),
+                                  _ptr(ws), nbytes, B, H, W_, Cin, Cout, ksize, 0, _stream()), "mad_conv_wgrad_edge")
+    return out
+
+
+def linear_backward(dy: Tensor, W: Tensor, xpre: Tensor, act_in: bool, need_dx: bool = True,
+                    dx: Optional[Tensor] = None, accumulate: bool = False):
+    """Backward of ``linear_f32(xpre, W, bias, act_in=act_in)``: returns (dx, dW, dbias); dx is the gradient
+    w.r.t. ``xpre`` (before the input activation) and may be accumulated into an existing tensor."""
+    _dev(dy, W, xpre, dx)
+    rows, N = dy.shape
+    K = W.shape[1]
+    if tuple(W.shape) != (N, K) or tuple(xpre.shape) != (rows, K) or dy.dtype != torch.float32:
+        raise ValueError("linear_backward: shape mismatch")
+    dy = dy.contiguous()
+    dW = torch.empty_like(W)
+    check(lib.mad_linear_bwd_weight(_ptr(dy), _ptr(xpre), _ptr(dW), rows, K, N, int(act_in), _stream()),
+          "mad_linear_bwd_weight")
+    db = bias_grad(dy)
+    if need_dx:
+        if dx is None:
+            dx, accumulate = torch.empty_like(xpre), False
+        check(lib.mad_linear_bwd_input(_ptr(dy), _ptr(W), _ptr(xpre), _ptr(dx), rows, K, N, int(act_in), int(accumulate),
+                                       _stream()), "mad_linear_bwd_input")
+    return dx, dW, db
+
+
+def dropout_(x: Tensor, seed: int, p: float) -> Tensor:
+    """In-place dropout with the counter-based mask of (seed, element index); p = 0 is a no-op."""
+    if p > 0.0:
+        _dev(x)
+        check(lib.mad_dropout(_ptr(x), _ptr(x), _dtype_code(x), x.numel(), seed, float(p), _stream()), "mad_dropout")
+    return x
+
+
+def mse_loss_grad(pred: Tensor, target: Tensor):
+    """(loss as a 0-dim device tensor, dloss/dpred) of F.mse_loss(pred, target), fp32."""
+    _dev(pred, target)
+    if pred.shape != target.shape or pred.dtype != torch.float32 or target.dtype != torch.float32:
+        raise ValueError("mse_loss_grad: fp32 tensors of one shape")
+    pred, target = pred.contiguous(), target.contiguous()
+    grad = torch.empty_like(pred)
+    nparts = 256
+    partial = torch.empty((nparts,), dtype=torch.float32, device=pred.device)
+    check(lib.mad_mse_loss_grad(_ptr(pred), _ptr(target), _ptr(grad), _ptr(partial), nparts, pred.numel(), _stream()),
+          "mad_mse_loss_grad")
+    return partial.sum() / pred.numel(), grad
+
+
+def adamw_step_(param: Tensor, grad: Tensor, m: Tensor, v: Tensor, ema: Optional[Tensor], lr: float, beta1: float,
+                beta2: float, eps: float, weight_decay: float, step: int, grad_scale: float = 1.0,
+                ema_decay: float = 0.0) -> None:
+    """Fused gradient clean-up + AdamW + EMA over flat fp32 buffers, in place."""
+    _dev(param, grad, m, v, ema)
+    n = param.numel()
+    for t in (param, grad, m, v) + ((ema,) if ema is not None else ()):
+        if t.dtype != torch.float32 or t.numel() != n or not t.is_contiguous():
+            raise ValueError("adamw_step_: flat contiguous fp32 buffers of one length")
+    check(lib.mad_adamw_step(_ptr(param), _ptr(grad), _ptr(m), _ptr(v), _ptr(ema), n, lr, beta1, beta2, eps, weight_decay,
+                             step, grad_scale, ema_decay, _stream()), "mad_adamw_step")
+
+
 GRAD_SAME, GRAD_FROM_HALF, GRAD_FROM_DOUBLE = 0, 1, 2     # resolution of a gradient tensor relative to x
 
 
@@ -535,7 +611,7 @@ def attention(qkv: Tensor, heads: int, want_lse: bool = False):
 
 
 def attention_backward(qkv: Tensor, out: Tensor, dout: Tensor, lse: Tensor, heads: int) -> Tensor:
-    """Gradient of ``attention`` w.r.t. qkv (same layout), bf16 only."""
+    """Gradient of ``attention`` w.r.t. qkv (same layout)."""
     _dev(qkv, out, dout, lse)
     B, H, W_, C3 = qkv.shape
     if out.shape != dout.shape or out.dtype != qkv.dtype or dout.dtype != qkv.dtype or not dout.is_contiguous():

@@ -1,0 +1,391 @@
+"""One training step of the denoiser on the HIP kernels: forward that keeps what the backward needs,
+hand-written backward, gradient all-reduce, fused AdamW + EMA.
+
+Mirrors the loop body of the reference's ``main.py:223-257`` (``/root/reference/main.py``):
+
+    t ~ randint, noise ~ randn, x_t = add_noise(x0, noise, t)            main.py:235-237
+    pred = model(x_t, t, class_labels=label)      (train mode: dropout)   main.py:240
+    loss = mse_loss(pred, noise); loss.backward()                        main.py:243-247
+    grads = nan_to_num(grads); AdamW step; EMA step                      main.py:248-257
+
+The reference differentiates with torch autograd; here every gradient is one of the kernels declared in
+``include/mad_hip.h`` (conv weight gradients on MFMA, data gradients through the forward conv kernels with
+transposed and flipped weights, GroupNorm/SiLU/AdaGN backward, flash-style attention backward, linear
+backward).  Activations are bf16 (or fp32), master weights / gradients / optimizer state fp32 in flat
+buffers, so the data-parallel gradient sum is a handful of large RCCL all-reduces over contiguous ranges.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional
+
+import torch
+from torch import Tensor
+
+from . import _lib, ops
+from .model import DhariwalUNet
+from .unet_spec import GN_EPS, BlockSpec, gn_groups
+
+
+def _dgrad_weight(w: Tensor) -> Tensor:
+    """(Cout,k,k,Cin) forward pack -> (Cin,k,k,Cout) with the taps flipped: the forward conv kernels then
+    compute the data gradient, dx = conv(dy, w')."""
+    return w.flip(1, 2).permute(3, 1, 2, 0).contiguous()
+
+
+class _Saved:
+    """What one UNetBlock's backward needs from its forward."""
+    __slots__ = ("x", "x_part", "skip", "skip_part", "c0", "h0", "h", "h_part", "c1", "h1", "seed", "y", "y_part",
+                 "c2", "hn", "qkv", "att", "lse")
+
+    def __init__(self):
+        for k in self.__slots__:
+            setattr(self, k, None)
+
+
+class UNetTrainer:
+    """Owns flat fp32 parameter / gradient / AdamW / EMA buffers of a ``DhariwalUNet`` and runs training steps."""
+
+    def __init__(self, unet: DhariwalUNet, lr: float = 1e-4, betas=(0.95, 0.999), eps: float = 1e-7,
+                 weight_decay: float = 1e-2, dropout: float = 0.10, ema: bool = True, ema_max_decay: float = 0.9999,
+                 ema_inv_gamma: float = 1.0, ema_power: float = 0.75, process_group=None, bucket_mb: int = 128,
+                 seed: int = 0):
+        self.unet = unet
+        self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+        self.dropout = float(dropout)
+        self.ema_cfg = (ema_max_decay, ema_inv_gamma, ema_power)
+        self.group = process_group
+        self.bucket_elems = bucket_mb * (1 << 20) // 4
+        self.step_count = 0
+        self.seed = seed
+        self._drop_calls = 0
+        params = list(unet.named_parameters())
+        if not params or not params[0][1].is_cuda:
+            raise RuntimeError("UNetTrainer needs the model on the GPU (the training step has no CPU path)")
+        dev = params[0][1].device
+        total = sum(p.numel() for _, p in params)
+        self.flat = torch.empty(total, dtype=torch.float32, device=dev)
+        self.gflat = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.m = torch.zeros_like(self.flat)
+        self.v = torch.zeros_like(self.flat)
+        self.grads: Dict[str, Tensor] = {}
+        off = 0
+        for name, p in params:
+            n = p.numel()
+            self.flat[off:off + n].copy_(p.data.reshape(-1).to(torch.float32))
+            p.data = self.flat[off:off + n].view(p.shape)
+            p.requires_grad_(False)
+            self.grads[name] = self.gflat[off:off + n].view(p.shape)
+            off += n
+        self.ema = self.flat.clone() if ema else None
+        unet.invalidate()
+
+    # ------------------------------------------------------------------ helpers
+    def _set(self, name: str, g: Tensor) -> None:
+        dst = self.grads[name]
+        dst.copy_(g.reshape(dst.shape))
+
+    @staticmethod
+    def _conv3(x: Tensor, w: Tensor, b: Optional[Tensor], upsample: bool = False, residual: Optional[Tensor] = None,
+               res_mode: int = _lib.RES_NONE, want_stats: bool = True):
+        """3x3 conv of a materialised input on whichever kernel covers the shape; returns (y, partials or None)."""
+        B, Hs, Ws, C = x.shape
+        H, W_ = (2 * Hs, 2 * Ws) if upsample else (Hs, Ws)
+        Cout = w.shape[0]
+        cm = 32 if x.dtype == torch.bfloat16 else 16
+        if ops.fused_conv_ok(H, W_, Cout) and C % cm == 0:
+            r = ops.conv3x3_fused(x, w, b, coef=None, upsample=upsample, residual=residual, res_mode=res_mode,
+                                  want_stats=want_stats)
+            return r if want_stats else (r, None)
+        stats = want_stats and (H * W_) % 64 == 0
+        r = ops.conv2d(x, w, b, residual=residual, res_mode=res_mode, upsample=upsample, want_stats=stats)
+        return r if stats else (r, None)
+
+    @staticmethod
+    def _dgrad3(dy: Tensor, wT: Tensor) -> Tensor:
+        """Data gradient of a 3x3 / 1x1 stride-1 conv: the forward kernels on the flipped, transposed weights."""
+        if wT.shape[1] == 3:
+            return UNetTrainer._conv3(dy, wT, None, want_stats=False)[0]
+        return ops.conv2d(dy, wT, None)
+
+    def _part(self, t: Tensor, part: Optional[Tensor]) -> Tensor:
+        return part if part is not None else ops.gn_partial(t)
+
+    # ------------------------------------------------------------------ forward (train mode)
+    def _block_fwd(self, e: dict, x: Tensor, x_part: Optional[Tensor], skip: Optional[Tensor],
+                   skip_part: Optional[Tensor], ada: Tensor, ada_total: int):
+        b: BlockSpec = e["spec"]
+        sv = _Saved()
+        hw_in, hw_out = b.res_in ** 2, b.res_out ** 2
+        sv.x, sv.skip = x, skip
+        sv.x_part = self._part(x, x_part)
+        sv.skip_part = None if skip is None else self._part(skip, skip_part)
+        sv.c0 = ops.gn_finalize(sv.x_part, hw_in, e["norm0.g"], e["norm0.b"], gn_groups(b.in_channels), GN_EPS,
+                                partial2=sv.skip_part)
+        ada_v = ada[:, e["ada_off"]:]
+        sv.h0 = ops.gn_apply(x, sv.c0, act=True, x2=skip, pool=b.down)
+        sv.h, sv.h_part = self._conv3(sv.h0, e["conv0.w"], e["conv0.b"], upsample=b.up)
+        sv.h_part = self._part(sv.h, sv.h_part)
+        sv.c1 = ops.gn_finalize(sv.h_part, hw_out, e["norm1.g"], e["norm1.b"], gn_groups(b.out_channels), GN_EPS,
+                                ada=ada_v, ada_stride=ada_total)
+        sv.h1 = ops.gn_apply(sv.h, sv.c1, act=True)
+        if self.dropout > 0.0:
+            self._drop_calls += 1
+            sv.seed = (self.seed << 32) ^ (self.step_count << 12) ^ self._drop_calls
+            ops.dropout_(sv.h1, sv.seed, self.dropout)
+        if b.skip_conv:
+            res, mode = ops.conv2d(x, e["skip.w"], e["skip.b"], x2=skip), _lib.RES_SAME
+        elif b.up:
+            res, mode = x, _lib.RES_UP
+        elif b.down:
+            res, mode = x, _lib.RES_DOWN
+        else:
+            res, mode = x, _lib.RES_SAME
+        sv.y, sv.y_part = self._conv3(sv.h1, e["conv1.w"], e["conv1.b"], residual=res, res_mode=mode)
+        out, out_part = sv.y, sv.y_part
+        if b.attention:
+            sv.y_part = self._part(sv.y, sv.y_part)
+            sv.c2 = ops.gn_finalize(sv.y_part, hw_out, e["norm2.g"], e["norm2.b"], gn_groups(b.out_channels), GN_EPS)
+            sv.hn = ops.gn_apply(sv.y, sv.c2, act=False)
+            sv.qkv = ops.conv2d(sv.hn, e["qkv.w"], e["qkv.b"])
+            sv.att, sv.lse = ops.attention(sv.qkv, b.num_heads, want_lse=True)
+            stats = hw_out % 64 == 0
+            r = ops.conv2d(sv.att, e["proj.w"], e["proj.b"], residual=sv.y, res_mode=_lib.RES_SAME, want_stats=stats)
+            out, out_part = r if stats else (r, None)
+        return out, out_part, sv
+
+    def forward(self, x: Tensor, t: Tensor, class_labels: Optional[Tensor]):
+        """Train-mode ``DhariwalUNet.forward`` (model.py:553-590); returns (pred NCHW fp32, tape)."""
+        u, s = self.unet, self.unet.spec
+        P = u._pack(x.device)
+        dt = P["dtype"]
+        B = x.shape[0]
+        x = x.to(torch.float32).contiguous()
+        t = t.to(device=x.device, dtype=torch.float32).reshape(-1).contiguous()
+        tape: dict = {"x": x, "P": P}
+        emb0 = ops.pos_embedding(t, P["freqs"], B)
+        pre1 = ops.linear_f32(emb0, P["map_layer0.weight"], P["map_layer0.bias"])
+        pre2 = ops.linear_f32(pre1, P["map_layer1.weight"], P["map_layer1.bias"], act_in=True)
+        lab = None
+        if s.label_dim:
+            lab = class_labels.to(device=x.device, dtype=torch.float32).reshape(-1, s.label_dim)
+            if lab.shape[0] == 1 and B > 1:
+                lab = lab.expand(B, -1)
+            lab = lab.contiguous()
+            ops.linear_f32(lab, P["map_label.weight"], None, out=pre2, accumulate=True)
+        ada = ops.linear_f32(pre2, P["aff.w"], P["aff.b"], act_in=True)
+        total = P["aff.total"]
+        tape.update(emb0=emb0, pre1=pre1, pre2=pre2, lab=lab, ada=ada)
+
+        h = ops.conv_in(x, P["in.w"], P["in.b"], dt)
+        h_part = None
+        skips = [(h, None)]
+        saved: List[_Saved] = []
+        n_enc = len(s.enc)
+        for i, e in enumerate(P["blocks"]):
+            b: BlockSpec = e["spec"]
+            if i < n_enc:
+                h, h_part, sv = self._block_fwd(e, h, h_part, None, None, ada, total)
+                skips.append((h, h_part))
+            else:
+                sk, sk_part = skips.pop() if b.cat_skip else (None, None)
+                h, h_part, sv = self._block_fwd(e, h, h_part, sk, sk_part, ada, total)
+            saved.append(sv)
+        R = s.img_resolution
+        h_part = self._part(h, h_part)
+        c = ops.gn_finalize(h_part, R * R, P["out_norm.g"], P["out_norm.b"], gn_groups(s.final_channels), GN_EPS)
+        hact = ops.gn_apply(h, c, act=True)
+        fused_out = R % 16 == 0 and s.out_channels <= 32 and s.final_channels % 32 == 0
+        if fused_out:
+            pred = ops.conv_out_fused(hact, P["out.w32"], P["out.b"], s.out_channels, coef=None)
+        else:
+            pred = ops.conv_out(hact, P["out.w"], P["out.b"])
+        tape.update(saved=saved, h_last=h, h_last_part=h_part, c_out=c, hact=hact)
+        return pred, tape
+
+    # ------------------------------------------------------------------ backward
+    def _block_bwd(self, e: dict, sv: _Saved, dout: Tensor, dskip_of_x: Optional[Tensor], dada: Tensor,
+                   ada: Tensor, ada_total: int):
+        """Gradients of one block's parameters; returns (dx, dskip): the gradients w.r.t. the block input and
+        w.r.t. the concatenated encoder skip (None without one).  ``dskip_of_x`` is the gradient that reaches
+        the block INPUT through its other use as a decoder skip."""
+        b: BlockSpec = e["spec"]
+        n = b.name
+        hw_out = b.res_out ** 2
+        ada_v, dada_v = ada[:, e["ada_off"]:], dada[:, e["ada_off"]:]
+        dy = dout
+        if b.attention:
+            self._set(f"{n}.proj.weight", ops.conv_wgrad(sv.att, dout, 1))
+            self._set(f"{n}.proj.bias", ops.bias_grad(dout))
+            datt = ops.conv2d(dout, _dgrad_weight(e["proj.w"]), None)
+            dqkv = ops.attention_backward(sv.qkv, sv.att, datt, sv.lse, b.num_heads)
+            # the packed qkv rows are a permutation of the reference's (model.py:359-363): undo it for the masters
+            co, heads = b.out_channels, b.num_heads
+            idx = torch.arange(3 * co, device=dout.device).reshape(heads, 64, 3).permute(0, 2, 1).reshape(-1)
+            gw = ops.conv_wgrad(sv.hn, dqkv, 1)
+            gb = ops.bias_grad(dqkv)
+            self.grads[f"{n}.qkv.weight"].index_copy_(0, idx, gw)
+            self.grads[f"{n}.qkv.bias"].index_copy_(0, idx, gb)
+            dhn = ops.conv2d(dqkv, _dgrad_weight(e["qkv.w"]), None)
+            dy, _, dg, db = ops.gn_backward(sv.y, dhn, sv.c2, sv.y_part, e["norm2.g"], e["norm2.b"],
+                                            gn_groups(b.out_channels), GN_EPS, act=False, add1=dout)
+            self._set(f"{n}.norm2.weight", dg)
+            self._set(f"{n}.norm2.bias", db)
+        # conv1 and the AdaGN in front of it
+        self._set(f"{n}.conv1.weight", ops.conv_wgrad(sv.h1, dy, 3))
+        self._set(f"{n}.conv1.bias", ops.bias_grad(dy))
+        dh1 = self._dgrad3(dy, _dgrad_weight(e["conv1.w"]))
+        if sv.seed is not None:
+            ops.dropout_(dh1, sv.seed, self.dropout)
+        dh, _, dg, db = ops.gn_backward(sv.h, dh1, sv.c1, sv.h_part, e["norm1.g"], e["norm1.b"],
+                                        gn_groups(b.out_channels), GN_EPS, act=True, ada=ada_v, ada_stride=ada_total,
+                                        dada=dada_v)
+        self._set(f"{n}.norm1.weight", dg)
+        self._set(f"{n}.norm1.bias", db)
+        # conv0 (input possibly resampled after norm0 + SiLU)
+        self._set(f"{n}.conv0.weight", ops.conv_wgrad(sv.h0, dh, 3, upsample=b.up))
+        self._set(f"{n}.conv0.bias", ops.bias_grad(dh))
+        dh0 = self._dgrad3(dh, _dgrad_weight(e["conv0.w"]))
+        mode0 = ops.GRAD_FROM_DOUBLE if b.up else (ops.GRAD_FROM_HALF if b.down else ops.GRAD_SAME)
+        # the residual branch's gradient w.r.t. the block input
+        if b.skip_conv:
+            xin = sv.x if sv.skip is None else torch.cat([sv.x, sv.skip], dim=-1)
+            self._set(f"{n}.skip.weight", ops.conv_wgrad(xin, dy, 1))
+            self._set(f"{n}.skip.bias", ops.bias_grad(dy))
+            dres, res_mode = ops.conv2d(dy, _dgrad_weight(e["skip.w"]), None), ops.GRAD_SAME
+        else:
+            dres, res_mode = dy, mode0
+        add2 = None
+        if dskip_of_x is not None:
+            if sv.skip is not None:          # the extra gradient covers x's channels only: widen it with zeros
+                pad = torch.zeros_like(sv.skip)
+                add2 = torch.cat([dskip_of_x, pad], dim=-1)
+            else:
+                add2 = dskip_of_x
+        dx, dskip, dg, db = ops.gn_backward(sv.x, dh0, sv.c0, sv.x_part, e["norm0.g"], e["norm0.b"],
+                                            gn_groups(b.in_channels), GN_EPS, act=True, x2=sv.skip,
+                                            stat2=sv.skip_part, dy_mode=mode0, add1=dres, add1_mode=res_mode,
+                                            add2=add2)
+        self._set(f"{n}.norm0.weight", dg)
+        self._set(f"{n}.norm0.bias", db)
+        return dx, dskip
+
+    def backward(self, tape: dict, dpred: Tensor) -> None:
+        """Fill ``self.grads`` from the gradient of the loss w.r.t. the prediction (NCHW fp32)."""
+        u, s = self.unet, self.unet.spec
+        P = tape["P"]
+        dt = P["dtype"]
+        B = dpred.shape[0]
+        total = P["aff.total"]
+        dev = dpred.device
+        # out_conv: weight gradient on the generic kernel, data gradient through the 3x3 kernel on a
+        # channel-padded NHWC copy of dpred
+        self._set("out_conv.weight", ops.conv_wgrad_edge(tape["hact"], False, dpred, True, 3))
+        self._set("out_conv.bias", dpred.sum((0, 2, 3)))
+        Cf, Co = s.final_channels, s.out_channels
+        pad_c = 32 if dt == torch.bfloat16 else 16
+        dp = torch.zeros((B, dpred.shape[2], dpred.shape[3], pad_c), dtype=dt, device=dev)
+        dp[..., :Co] = dpred.permute(0, 2, 3, 1).to(dt)
+        wT = torch.zeros((Cf, 3, 3, pad_c), dtype=dt, device=dev)
+        wT[..., :Co] = P["out.w"].flip(1, 2).permute(3, 1, 2, 0).to(dt)
+        dhact = self._dgrad3(dp, wT)
+        dh, _, dg, db = ops.gn_backward(tape["h_last"], dhact, tape["c_out"], tape["h_last_part"], P["out_norm.g"],
+                                        P["out_norm.b"], gn_groups(Cf), GN_EPS, act=True)
+        self._set("out_norm.weight", dg)
+        self._set("out_norm.bias", db)
+
+        dada = torch.zeros_like(tape["ada"])
+        saved: List[_Saved] = tape["saved"]
+        n_enc = len(s.enc)
+        # skip gradients: the decoder (walked backwards) appends d a_0, d a_1, ... for the encoder chain's
+        # activations a_0 = first conv, a_i = encoder block i-1; the consumers then take them from the end
+        pending: List[Tensor] = []
+        blocks = P["blocks"]
+        for i in range(len(blocks) - 1, -1, -1):
+            e, sv = blocks[i], saved[i]
+            b: BlockSpec = e["spec"]
+            # the input of encoder block i>0 (and of the first decoder block) is also a decoder skip
+            extra = pending.pop() if self._input_is_skip(i, n_enc) else None
+            dh, dskip = self._block_bwd(e, sv, dh, extra, dada, tape["ada"], total)
+            if dskip is not None:
+                pending.append(dskip)
+        # what is left is the skip gradient of the first conv's output
+        if pending:
+            dh = dh + pending.pop(0)
+        assert not pending, "unconsumed skip gradients"
+        self._set(f"{s.enc_conv_name}.weight", ops.conv_wgrad_edge(tape["x"], True, dh, False, 3))
+        self._set(f"{s.enc_conv_name}.bias", ops.bias_grad(dh))
+
+        # embedding MLP: ada = aff(silu(pre2)), pre2 = lin1(silu(pre1)) + label(lab), pre1 = lin0(emb0)
+        dpre2, gw, gb = ops.linear_backward(dada, P["aff.w"], tape["pre2"], act_in=True)
+        off = 0
+        for e in blocks:
+            n, co2 = e["spec"].name, 2 * e["spec"].out_channels
+            self._set(f"{n}.affine.weight", gw[off:off + co2])
+            self._set(f"{n}.affine.bias", gb[off:off + co2])
+            off += co2
+        if s.label_dim:
+            _, gl, _ = ops.linear_backward(dpre2, P["map_label.weight"], tape["lab"], act_in=False, need_dx=False)
+            self._set("map_label.weight", gl)
+        dpre1, gw, gb = ops.linear_backward(dpre2, P["map_layer1.weight"], tape["pre1"], act_in=True)
+        self._set("map_layer1.weight", gw)
+        self._set("map_layer1.bias", gb)
+        _, gw, gb = ops.linear_backward(dpre1, P["map_layer0.weight"], tape["emb0"], act_in=False, need_dx=False)
+        self._set("map_layer0.weight", gw)
+        self._set("map_layer0.bias", gb)
+
+    @staticmethod
+    def _input_is_skip(i: int, n_enc: int) -> bool:
+        """Block i's input is output i-1 of the encoder chain (index 0 = the first conv); every encoder
+        output, the last one included, is popped as a skip by some decoder block (model.py:578-588)."""
+        return 1 <= i <= n_enc
+
+    # ------------------------------------------------------------------ step
+    def forward_backward(self, x_t: Tensor, t: Tensor, class_labels: Optional[Tensor], target: Tensor) -> Tensor:
+        self._drop_calls = 0
+        pred, tape = self.forward(x_t, t, class_labels)
+        loss, dpred = ops.mse_loss_grad(pred, target.to(torch.float32))
+        self.backward(tape, dpred)
+        return loss
+
+    def sync_grads(self) -> None:
+        """Sum the gradients over the data-parallel ranks: a few large all-reduces over contiguous ranges
+        of the flat buffer (RCCL on GPUs); the division by the world size is folded into the update."""
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(self.group) == 1:
+            return
+        n = self.gflat.numel()
+        works = [dist.all_reduce(self.gflat[o:min(o + self.bucket_elems, n)], group=self.group, async_op=True)
+                 for o in range(0, n, self.bucket_elems)]
+        for w in works:
+            w.wait()
+
+    def ema_decay(self) -> float:
+        """diffusers ``EMAModel.get_decay`` with warm-up (main.py:153-159): 1 - (1 + step/inv_gamma)^-power."""
+        max_decay, inv_gamma, power = self.ema_cfg
+        step = max(0, self.step_count - 1)
+        if step <= 0:
+            return 0.0
+        return max(0.0, min(max_decay, 1.0 - (1.0 + step / inv_gamma) ** -power))
+
+    def step(self, lr: Optional[float] = None, world_size: int = 1) -> None:
+        self.step_count += 1
+        ops.adamw_step_(self.flat, self.gflat, self.m, self.v, self.ema, self.lr if lr is None else lr, self.betas[0],
+                        self.betas[1], self.eps, self.weight_decay, self.step_count, grad_scale=1.0 / world_size,
+                        ema_decay=self.ema_decay())
+        self.unet.invalidate()
+
+    def train_step(self, x0: Tensor, class_labels: Optional[Tensor], alphas_cumprod: Tensor,
+                   generator: Optional[torch.Generator] = None, num_timesteps: int = 1000) -> Tensor:
+        """main.py:235-257 for one batch of clean images x0 (NCHW fp32 in [-1, 1])."""
+        import torch.distributed as dist
+        B = x0.shape[0]
+        t = torch.randint(0, num_timesteps, (B,), device=x0.device, generator=generator)
+        noise = torch.randn(x0.shape, device=x0.device, dtype=torch.float32, generator=generator)
+        a = alphas_cumprod.to(x0.device)[t].to(torch.float32)
+        x_t = a.sqrt().view(B, 1, 1, 1) * x0 + (1.0 - a).sqrt().view(B, 1, 1, 1) * noise
+        loss = self.forward_backward(x_t, t.to(torch.float32), class_labels, noise)
+        self.sync_grads()
+        ws = dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
+        self.step(world_size=ws)
+        return loss

@@ -1,0 +1,119 @@
+"""The training step (forward with tape, hand-written backward, AdamW + EMA) against autograd through the
+CPU restatement of the reference's denoiser (GPU only)."""
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import REPO, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _grad_on():
+    with torch.enable_grad():
+        yield
+
+
+@pytest.fixture(scope="module")
+def dev():
+    return torch.device("cuda:0")
+
+
+def _setup(cfg_file, precision, dev, B, seed=3):
+    from mad_amd.config import load_cfg
+    from mad_amd.model import build_model
+    from mad_amd.synthetic import synthetic_faces
+    cfg = load_cfg(os.path.join(REPO, "configs", cfg_file))
+    m = build_model(cfg, precision=precision)
+    m.unet.init_seeded(seed)
+    sd = {k: v.detach().clone().float() for k, v in m.unet.state_dict().items()}
+    m = m.to(dev).train()
+    R = m.unet.spec.img_resolution
+    g = torch.Generator().manual_seed(11)
+    x = synthetic_faces(B, R, seed=5) * 0.7 + 0.5 * torch.randn(B, 3, R, R, generator=g)
+    t = torch.tensor([37.0, 611.0, 250.0, 900.0][:B])
+    lab = torch.eye(2)[torch.arange(B) % 2]
+    target = torch.randn(B, 3, R, R, generator=g)
+    return cfg, m, sd, x, t, lab, target
+
+
+def _oracle_grads(cfg, sd, x, t, lab, target):
+    from oracle import unet_ref
+    from mad_amd.unet_spec import spec_from_cfg
+    s = spec_from_cfg(cfg)
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items() if "resample_filter" not in k}
+    full = dict(sd)
+    full.update(params)
+    pred = unet_ref.unet_forward(full, x, t, lab, img_resolution=s.img_resolution, model_channels=s.model_channels,
+                                 channel_mult=s.channel_mult, num_blocks=s.num_blocks, label_dim=s.label_dim)
+    loss = F.mse_loss(pred, target)
+    loss.backward()
+    return float(loss.detach()), pred.detach(), {k: v.grad for k, v in params.items()}
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_train_gradients_match_autograd(dev, precision):
+    from mad_amd.train import UNetTrainer
+    cfg, m, sd, x, t, lab, target = _setup("model_tiny.yaml", precision, dev, B=3)
+    want_loss, want_pred, want = _oracle_grads(cfg, sd, x, t, lab, target)
+    tr = UNetTrainer(m.unet, dropout=0.0)
+    pred, tape = tr.forward(x.to(dev), t.to(dev), lab.to(dev))
+    tol_out = 1e-4 if precision == "fp32" else 3e-2
+    assert rel_err(pred.cpu(), want_pred) < tol_out
+    loss = tr.forward_backward(x.to(dev), t.to(dev), lab.to(dev), target.to(dev))
+    assert abs(float(loss) - want_loss) < (1e-4 if precision == "fp32" else 2e-2) * want_loss
+    tol = 2e-3 if precision == "fp32" else 6e-2
+    worst = ("", 0.0)
+    assert set(tr.grads) == set(want)
+    for k, g in want.items():
+        assert g is not None, k
+        err = rel_err(tr.grads[k].cpu(), g)
+        if err > worst[1]:
+            worst = (k, err)
+    print(f"{precision}: worst gradient rel err {worst[1]:.3e} at {worst[0]}")
+    assert worst[1] < tol, worst
+
+
+def test_adamw_ema_step_matches_torch(dev):
+    """Flat fused update against torch.optim.AdamW (+ nan_to_num and the EMA rule) on random buffers."""
+    from mad_amd import ops
+    g = torch.Generator().manual_seed(1)
+    n = 100003
+    p0, grad = torch.randn(n, generator=g), torch.randn(n, generator=g) * 0.1
+    grad[5], grad[6], grad[7] = float("nan"), float("inf"), float("-inf")
+    ref = torch.nn.Parameter(p0.clone().double())
+    opt = torch.optim.AdamW([ref], lr=1e-3, betas=(0.95, 0.999), eps=1e-7, weight_decay=1e-2)
+    p, m, v, ema = p0.clone().to(dev), torch.zeros(n, device=dev), torch.zeros(n, device=dev), p0.clone().to(dev)
+    ema_ref = p0.clone().double()
+    for step in range(1, 4):
+        gd = torch.nan_to_num(grad.double() * 0.5, nan=0.0, posinf=1e5, neginf=-1e5) * step
+        ref.grad = gd.clone()
+        opt.step()
+        decay = 0.9 if step > 1 else 0.0
+        ema_ref -= (1 - decay) * (ema_ref - ref.detach())
+        ops.adamw_step_(p, (grad * step).to(dev), m, v, ema, 1e-3, 0.95, 0.999, 1e-7, 1e-2, step, grad_scale=0.5,
+                        ema_decay=decay)
+    assert rel_err(p.cpu(), ref.detach()) < 1e-4
+    assert rel_err(ema.cpu(), ema_ref) < 1e-4
+
+
+def test_training_reduces_loss(dev):
+    """Full steps (dropout on) on one fixed noised batch: the loss goes down and the EMA follows."""
+    from mad_amd.train import UNetTrainer
+    cfg, m, sd, x0, _, lab, noise = _setup("model_tiny.yaml", "bf16", dev, B=4)
+    t = torch.tensor([500.0, 700.0, 900.0, 999.0])
+    betas = torch.linspace(1e-4, 2e-2, 1000)
+    a = torch.cumprod(1 - betas, 0)[t.long()].view(4, 1, 1, 1)
+    x_t = a.sqrt() * x0.clamp(-1, 1) + (1 - a).sqrt() * noise
+    tr = UNetTrainer(m.unet, lr=5e-4, dropout=0.1)
+    losses = []
+    for _ in range(30):
+        losses.append(float(tr.forward_backward(x_t.to(dev), t.to(dev), lab.to(dev), noise.to(dev))))
+        tr.step()
+    print("losses", [round(v, 4) for v in losses])
+    assert min(losses[-5:]) < 0.8 * losses[0]
+    assert torch.isfinite(tr.flat).all() and torch.isfinite(tr.ema).all()
+    assert float((tr.ema - tr.flat).abs().max()) > 0
