@@ -33,7 +33,7 @@ def parse_args():
     p.add_argument("--batch", type=int, default=32, help="images per GPU per step")
     p.add_argument("--num-of-step", type=int, default=700,
                    help="start_from_step of the removal loop (reference default 700)")
-    p.add_argument("--workload", default="removal", choices=["removal", "transfer"],
+    p.add_argument("--workload", default="removal", choices=["removal", "transfer", "train"],
                    help="removal: domain_translation (headline); transfer: image_translation with inpainting and "
                         "per-step component masks, S = 180 (a secondary configuration, not the headline)")
     p.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
@@ -121,6 +121,12 @@ def hbm_kernels(dev, B, R, C, iters=20):
 
 def main():
     args = parse_args()
+    if args.workload == "train":
+        # the DDP training step has its own driver (same launch contract and JSON line)
+        import bench_train
+        sys.argv = [sys.argv[0], "--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup),
+                    "--config", args.config, "--precision", args.precision] + (["--no-cpu-baseline"] if args.no_cpu_baseline else [])
+        return bench_train.main()
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

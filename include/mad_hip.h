@@ -288,8 +288,10 @@ int mad_conv_wgrad_edge(const void* x, int x_dtype, int x_nchw, const void* dy, 
  *   input : dx[r,k] (+)= (sum_n dy[r,n]*W[n,k]) * (act_in ? silu'(xpre[r,k]) : 1)   (xpre may be NULL without act_in)
  *   weight: dW[n,k]   = sum_r dy[r,n] * act_in(xpre[r,k])        (bias: mad_bias_grad over dy)
  * Autograd of Linear.forward (model.py:60-64). */
-int mad_linear_bwd_input(const float* dy, const float* W, const float* xpre, float* dx, int rows, int K,
-                         int N, int act_in, int accumulate, void* stream);
+size_t mad_linear_bwd_input_workspace(int rows, int K, int N);
+int mad_linear_bwd_input(const float* dy, const float* W, const float* xpre, float* dx, void* workspace,
+                         size_t workspace_bytes, int rows, int K, int N, int act_in, int accumulate,
+                         void* stream);
 int mad_linear_bwd_weight(const float* dy, const float* xpre, float* dW, int rows, int K, int N,
                           int act_in, void* stream);
 

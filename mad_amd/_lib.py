@@ -67,7 +67,8 @@ SIGNATURES = {
     "mad_conv_wgrad_edge_workspace": (ctypes.c_size_t, [c_int] * 6),
     "mad_conv_wgrad_edge": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, ctypes.c_size_t] +
                             [c_int] * 7 + [c_void_p]),
-    "mad_linear_bwd_input": (c_int, [c_void_p] * 4 + [c_int] * 5 + [c_void_p]),
+    "mad_linear_bwd_input_workspace": (ctypes.c_size_t, [c_int] * 3),
+    "mad_linear_bwd_input": (c_int, [c_void_p] * 5 + [ctypes.c_size_t] + [c_int] * 5 + [c_void_p]),
     "mad_linear_bwd_weight": (c_int, [c_void_p] * 3 + [c_int] * 4 + [c_void_p]),
     "mad_dropout": (c_int, [c_void_p, c_void_p, c_int, ctypes.c_size_t, ctypes.c_ulonglong, c_float, c_void_p]),
     "mad_mse_loss_grad": (c_int, [c_void_p] * 4 + [c_int, ctypes.c_size_t, c_void_p]),

@@ -10,26 +10,36 @@ __device__ __forceinline__ float silu_grad_t(float u) {
     return s * fmaf(u, 1.0f - s, 1.0f);
 }
 
-// dX[r,k] = (sum_n dY[r,n] * W[n,k]) * (act_in ? silu'(xpre[r,k]) : 1); grid (ceil(K/256), rows)
-__global__ __launch_bounds__(256) void linear_dx_kernel(const float* __restrict__ dy, const float* __restrict__ w,
-                                                         const float* __restrict__ xpre, float* __restrict__ dx, int N,
-                                                         int K, int act_in, int accumulate) {
+// part[z][r][k] = sum over the z-th share of n of dY[r,n] * W[n,k]; grid (ceil(K/256), rows, nsplit)
+__global__ __launch_bounds__(256) void linear_dx_partial_kernel(const float* __restrict__ dy, const float* __restrict__ w,
+                                                                 float* __restrict__ part, int rows, int N, int K) {
     const int k = blockIdx.x * 256 + threadIdx.x, r = blockIdx.y;
     if (k >= K) return;
+    const int per = (N + gridDim.z - 1) / gridDim.z;
+    const int n0 = blockIdx.z * per, n1 = n0 + per < N ? n0 + per : N;
     const float* g = dy + (size_t)r * N;
     float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
-    int n = 0;
-    for (; n + 4 <= N; n += 4) {
+    int n = n0;
+    for (; n + 4 <= n1; n += 4) {
         s0 = fmaf(g[n], w[(size_t)n * K + k], s0);
         s1 = fmaf(g[n + 1], w[(size_t)(n + 1) * K + k], s1);
         s2 = fmaf(g[n + 2], w[(size_t)(n + 2) * K + k], s2);
         s3 = fmaf(g[n + 3], w[(size_t)(n + 3) * K + k], s3);
     }
-    for (; n < N; ++n) s0 = fmaf(g[n], w[(size_t)n * K + k], s0);
-    float s = (s0 + s1) + (s2 + s3);
-    if (act_in) s *= silu_grad_t(xpre[(size_t)r * K + k]);
-    float* o = dx + (size_t)r * K + k;
-    *o = accumulate ? *o + s : s;
+    for (; n < n1; ++n) s0 = fmaf(g[n], w[(size_t)n * K + k], s0);
+    part[((size_t)blockIdx.z * rows + r) * K + k] = (s0 + s1) + (s2 + s3);
+}
+
+// dX[i] (+)= (sum_z part[z][i]) * (act_in ? silu'(xpre[i]) : 1), shares added in a fixed order
+__global__ __launch_bounds__(256) void linear_dx_finish_kernel(const float* __restrict__ part, const float* __restrict__ xpre,
+                                                                float* __restrict__ dx, int n, int nsplit, int act_in,
+                                                                int accumulate) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.0f;
+    for (int z = 0; z < nsplit; ++z) s += part[(size_t)z * n + i];
+    if (act_in) s *= silu_grad_t(xpre[i]);
+    dx[i] = accumulate ? dx[i] + s : s;
 }
 
 // dW[n,k] = sum_r dY[r,n] * (act_in ? silu(xpre[r,k]) : xpre[r,k]); grid (ceil(K/256), N)
@@ -121,13 +131,25 @@ __global__ __launch_bounds__(256) void adamw_kernel(AdamArgs a) {
 
 using namespace mad;
 
-extern "C" int mad_linear_bwd_input(const float* dy, const float* W, const float* xpre, float* dx, int rows, int K,
-                                    int N, int act_in, int accumulate, void* stream) {
-    MAD_REQUIRE(dy && W && dx && (!act_in || xpre), "mad_linear_bwd_input: null pointer");
+static int linear_dx_splits(int N) { const int z = N / 512; return z < 1 ? 1 : (z > 64 ? 64 : z); }
+
+extern "C" size_t mad_linear_bwd_input_workspace(int rows, int K, int N) {
+    return (size_t)linear_dx_splits(N) * rows * K * sizeof(float);
+}
+
+extern "C" int mad_linear_bwd_input(const float* dy, const float* W, const float* xpre, float* dx, void* workspace,
+                                    size_t workspace_bytes, int rows, int K, int N, int act_in, int accumulate,
+                                    void* stream) {
+    MAD_REQUIRE(dy && W && dx && workspace && (!act_in || xpre), "mad_linear_bwd_input: null pointer");
     MAD_REQUIRE(rows > 0 && K > 0 && N > 0, "mad_linear_bwd_input: bad shape");
-    hipLaunchKernelGGL(linear_dx_kernel, dim3((K + 255) / 256, rows), dim3(256), 0, (hipStream_t)stream, dy, W, xpre, dx,
-                       N, K, act_in, accumulate);
-    return check_launch("mad_linear_bwd_input");
+    MAD_REQUIRE(workspace_bytes >= mad_linear_bwd_input_workspace(rows, K, N), "mad_linear_bwd_input: workspace too small");
+    const int z = linear_dx_splits(N);
+    hipLaunchKernelGGL(linear_dx_partial_kernel, dim3((K + 255) / 256, rows, z), dim3(256), 0, (hipStream_t)stream, dy, W,
+                       (float*)workspace, rows, N, K);
+    if (int rc = check_launch("mad_linear_bwd_input")) return rc;
+    hipLaunchKernelGGL(linear_dx_finish_kernel, dim3((rows * K + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)workspace, xpre, dx, rows * K, z, act_in, accumulate);
+    return check_launch("mad_linear_bwd_input (finish)");
 }
 
 extern "C" int mad_linear_bwd_weight(const float* dy, const float* xpre, float* dW, int rows, int K, int N, int act_in,

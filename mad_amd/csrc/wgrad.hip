@@ -171,20 +171,44 @@ __global__ __launch_bounds__(256) void wgrad_generic_kernel(WgradGenArgs a) {
     }
 }
 
-// dst[i] (+)= sum over s of partial[s][i], in the order s = 0, 1, ...; optionally scattering from the
-// (Cout, taps, Cin) order of the partials to the (Cout, Cin, taps) order of the master weights.
+// dst[i] (+)= sum over s of partial[s][i], in the order s = 0, 1, ... (taps == 0: plain vectors).
 __global__ void wgrad_reduce_kernel(const float* partial, float* dst, size_t n, int nsplit, int accumulate, int taps,
                                     int Cin) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float s = 0.0f;
     for (int k = 0; k < nsplit; ++k) s += partial[(size_t)k * n + i];
-    size_t o = i;
-    if (taps > 0) {                                       // i = (co*taps + t)*Cin + ci  ->  (co*Cin + ci)*taps + t
-        const size_t ci = i % Cin, r = i / Cin, t = r % taps, co = r / taps;
-        o = (co * Cin + ci) * taps + t;
+    dst[i] = accumulate ? dst[i] + s : s;
+}
+
+// The same sum for conv weights: the partials are (Cout, taps, Cin), the master weights (Cout, Cin, taps).
+// One workgroup = one output channel x 32 input channels; the block is transposed through LDS so both
+// sides stay coalesced.  grid (Cout, ceil(Cin/32)).
+__global__ __launch_bounds__(288) void wgrad_reduce_oihw_kernel(const float* partial, float* dst, int Cout, int nsplit,
+                                                                 int accumulate, int taps, int Cin) {
+    __shared__ float blk[9 * 32];                         // [taps][32]
+    const int co = blockIdx.x, c0 = blockIdx.y * 32;
+    const int cw = Cin - c0 < 32 ? Cin - c0 : 32;
+    const size_t n = (size_t)Cout * taps * Cin;
+    const int t = threadIdx.x >> 5, cl = threadIdx.x & 31;
+    if (t < taps && cl < cw) {
+        const float* p = partial + ((size_t)co * taps + t) * Cin + c0 + cl;
+        float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+        int k = 0;
+        for (; k + 4 <= nsplit; k += 4) {
+            s0 += p[(size_t)k * n]; s1 += p[(size_t)(k + 1) * n]; s2 += p[(size_t)(k + 2) * n]; s3 += p[(size_t)(k + 3) * n];
+        }
+        for (; k < nsplit; ++k) s0 += p[(size_t)k * n];
+        blk[t * 32 + cl] = (s0 + s1) + (s2 + s3);
     }
-    dst[o] = accumulate ? dst[o] + s : s;
+    __syncthreads();
+    const int o = threadIdx.x;                            // position inside the (cw, taps) output block
+    if (o < cw * taps) {
+        const int ci = o / taps, tt = o - ci * taps;
+        float* d = dst + ((size_t)co * Cin + c0) * taps + o;
+        const float v = blk[tt * 32 + ci];
+        *d = accumulate ? *d + v : v;
+    }
 }
 
 // Column sums of a (rows, C) matrix, rows split over blockIdx.y: partial[split][c].
@@ -195,6 +219,70 @@ template <typename T> __global__ __launch_bounds__(256) void colsum_kernel(const
     float s = 0.0f;
     for (long r = blockIdx.y; r < rows; r += gridDim.y) s += Elem<T>::load(x[r * sr + c * sc]);
     partial[(size_t)blockIdx.y * C + c] = s;
+}
+
+// First / last layer: one operand is channels-last with many channels (V: dY of the first conv, X of the
+// last), the other is the NCHW fp32 image side with at most 4 channels (S).  A thread owns one V channel
+// and keeps all (S channel, tap) sums in registers, so V is read exactly once, coalesced over channels;
+// the S values of a pixel's 3x3 neighbourhood are the same for every thread of a pixel row group.
+//   acc[cs][t] = sum_p V[p][cv] * S[cs][p + sgn*(tap offset)]      (sgn = +1 first layer, -1 last layer)
+struct WgradEdgeArgs {
+    const void* v; const float* s; float* partial;
+    int B, H, W, CV, CS, sgn, nsplit;
+};
+
+template <typename TV>
+__global__ __launch_bounds__(256) void wgrad_edge_kernel(WgradEdgeArgs a) {
+    __shared__ float red[256 * 36];
+    const int rows = 256 / a.CV > 0 ? 256 / a.CV : 1;           // pixel streams per workgroup (CV <= 256)
+    const int cv = threadIdx.x % a.CV, r = threadIdx.x / a.CV;
+    const bool active = r < rows;
+    const TV* V = (const TV*)a.v;
+    const long npix = (long)a.B * a.H * a.W;
+    const long per = (npix + a.nsplit - 1) / a.nsplit;
+    const long p0 = (long)blockIdx.x * per, p1 = p0 + per < npix ? p0 + per : npix;
+    float acc[4][9];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc[c][t] = 0.0f;
+    if (active) {
+        for (long p = p0 + r; p < p1; p += rows) {
+            const int x = (int)(p % a.W), y = (int)((p / a.W) % a.H), b = (int)(p / ((long)a.W * a.H));
+            const float v = Elem<TV>::load(V[p * a.CV + cv]);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int yy = y + a.sgn * (t / 3 - 1), xx = x + a.sgn * (t % 3 - 1);
+                if (yy < 0 || yy >= a.H || xx < 0 || xx >= a.W) continue;
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    if (c < a.CS) acc[c][t] = fmaf(v, a.s[(((long)b * a.CS + c) * a.H + yy) * a.W + xx], acc[c][t]);
+            }
+        }
+    }
+    // sum the pixel streams of this workgroup, then one row of partials per workgroup
+    for (int c = 0; c < 4; ++c)
+        for (int t = 0; t < 9; ++t) red[threadIdx.x * 36 + c * 9 + t] = active ? acc[c][t] : 0.0f;
+    __syncthreads();
+    if (threadIdx.x < a.CV) {
+        for (int j = 0; j < 36; ++j) {
+            float sum = 0.0f;
+            for (int rr = 0; rr < rows; ++rr) sum += red[(rr * a.CV + cv) * 36 + j];
+            a.partial[((size_t)blockIdx.x * a.CV + cv) * 36 + j] = sum;
+        }
+    }
+}
+
+// dw (OIHW) = sum over splits of partial[split][cv][cs*9+t]; first layer: (O, I) = (cv, cs); last: (cs, cv)
+__global__ void wgrad_edge_reduce_kernel(const float* partial, float* dw, int nsplit, int CV, int CS, int v_is_out,
+                                         int accumulate) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= CV * CS * 9) return;
+    const int t = i % 9, cs = (i / 9) % CS, cv = i / (9 * CS);
+    float s = 0.0f;
+    for (int k = 0; k < nsplit; ++k) s += partial[((size_t)k * CV + cv) * 36 + cs * 9 + t];
+    const int o = v_is_out ? (cv * CS + cs) * 9 + t : (cs * CV + cv) * 9 + t;
+    dw[o] = accumulate ? dw[o] + s : s;
 }
 
 static int pick_ksplit(int slices, int ntiles) {
@@ -266,9 +354,8 @@ extern "C" int mad_conv_wgrad(const void* x, const void* dy, float* dw, void* wo
         else hipLaunchKernelGGL((wgrad_generic_kernel<float, float>), grid, dim3(256), 0, s, a);
     }
     if (int rc = check_launch("mad_conv_wgrad")) return rc;
-    const size_t n = (size_t)Cout * nt * Cin;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const float*)workspace,
-                       dw, n, ksplit, accumulate, nt, Cin);
+    hipLaunchKernelGGL(wgrad_reduce_oihw_kernel, dim3(Cout, (Cin + 31) / 32), dim3(288), 0, s,
+                       (const float*)workspace, dw, Cout, ksplit, accumulate, nt, Cin);
     return check_launch("mad_conv_wgrad (reduce)");
 }
 
@@ -296,8 +383,17 @@ extern "C" int mad_bias_grad(const void* dy, int dtype, long rows, int C, float*
 }
 
 // First / last layer: operands in different dtypes and layouts (the image side is NCHW fp32).
+static int edge_splits(int B, int H, int W) {
+    const long npix = (long)B * H * W;
+    long k = npix / 256;                                   // at least 256 pixels per workgroup
+    return (int)(k < 1 ? 1 : (k > 1024 ? 1024 : k));
+}
+
 extern "C" size_t mad_conv_wgrad_edge_workspace(int B, int H, int W, int Cin, int Cout, int ksize) {
-    return mad_conv_wgrad_workspace(MAD_F32, B, H, W, Cin, Cout, ksize);      // MAD_F32 always takes the generic split
+    const size_t generic = mad_conv_wgrad_workspace(MAD_F32, B, H, W, Cin, Cout, ksize);   // MAD_F32: the generic split
+    const int cv = Cin > Cout ? Cin : Cout;
+    const size_t edge = (size_t)edge_splits(B, H, W) * cv * 36 * sizeof(float);
+    return generic > edge ? generic : edge;
 }
 
 extern "C" int mad_conv_wgrad_edge(const void* x, int x_dtype, int x_nchw, const void* dy, int dy_dtype, int dy_nchw,
@@ -312,6 +408,23 @@ extern "C" int mad_conv_wgrad_edge(const void* x, int x_dtype, int x_nchw, const
                 "mad_conv_wgrad_edge: workspace of %zu bytes is too small", workspace_bytes);
     hipStream_t s = (hipStream_t)stream;
     const int nt = ksize * ksize;
+    // the two shapes of the denoiser: first conv (image in, channels-last gradient) and last conv
+    const bool first = ksize == 3 && x_nchw && x_dtype == MAD_F32 && !dy_nchw && Cin <= 4 && Cout <= 256;
+    const bool last = ksize == 3 && !x_nchw && dy_nchw && dy_dtype == MAD_F32 && Cout <= 4 && Cin <= 256;
+    if (first || last) {
+        WgradEdgeArgs e;
+        e.v = first ? dy : x; e.s = (const float*)(first ? x : dy); e.partial = (float*)workspace;
+        e.B = B; e.H = H; e.W = W; e.CV = first ? Cout : Cin; e.CS = first ? Cin : Cout; e.sgn = first ? 1 : -1;
+        e.nsplit = edge_splits(B, H, W);
+        const int vdt = first ? dy_dtype : x_dtype;
+        if (vdt == MAD_BF16) hipLaunchKernelGGL(wgrad_edge_kernel<bf16_t>, dim3(e.nsplit), dim3(256), 0, s, e);
+        else hipLaunchKernelGGL(wgrad_edge_kernel<float>, dim3(e.nsplit), dim3(256), 0, s, e);
+        if (int rc = check_launch("mad_conv_wgrad_edge")) return rc;
+        const int n = e.CV * e.CS * 9;
+        hipLaunchKernelGGL(wgrad_edge_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, s, (const float*)workspace, dw,
+                           e.nsplit, e.CV, e.CS, first ? 1 : 0, accumulate);
+        return check_launch("mad_conv_wgrad_edge (reduce)");
+    }
     const int ksplit = wgrad_ksplit(MAD_F32, B, H, W, Cin, Cout, ksize, nullptr);
     WgradGenArgs a;
     a.x = x; a.dy = dy; a.partial = (float*)workspace; a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
@@ -326,8 +439,7 @@ extern "C" int mad_conv_wgrad_edge(const void* x, int x_dtype, int x_nchw, const
     else if (dy_dtype == MAD_F32) hipLaunchKernelGGL((wgrad_generic_kernel<bf16_t, float>), grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL((wgrad_generic_kernel<bf16_t, bf16_t>), grid, dim3(256), 0, s, a);
     if (int rc = check_launch("mad_conv_wgrad_edge")) return rc;
-    const size_t n = (size_t)Cout * nt * Cin;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const float*)workspace,
-                       dw, n, ksplit, accumulate, nt, Cin);
+    hipLaunchKernelGGL(wgrad_reduce_oihw_kernel, dim3(Cout, (Cin + 31) / 32), dim3(288), 0, s,
+                       (const float*)workspace, dw, Cout, ksplit, accumulate, nt, Cin);
     return check_launch("mad_conv_wgrad_edge (reduce)");
 }

@@ -403,6 +403,11 @@ def bias_grad(dy: Tensor, out: Optional[Tensor] = None, accumulate: bool = False
     """Sum of dy (..., C) over every axis but the last, fp32 (C,)."""
     _dev(dy, out)
     C = dy.shape[-1]
+    if dy.dim() == 4 and dy.is_contiguous() and C % (8 if dy.dtype == torch.bfloat16 else 4) == 0 \
+            and dy.shape[1] * dy.shape[2] >= 256:
+        # large activations: the vectorised statistics kernel's sums, then the column sum of its small output
+        part = gn_partial(dy)
+        return bias_grad(part[..., 0].reshape(-1, C).contiguous(), out=out, accumulate=accumulate)
     rows = dy.numel() // C
     if not dy.is_contiguous():
         raise ValueError("bias_grad: dy must be contiguous")
@@ -452,8 +457,10 @@ def linear_backward(dy: Tensor, W: Tensor, xpre: Tensor, act_in: bool, need_dx: 
     if need_dx:
         if dx is None:
             dx, accumulate = torch.empty_like(xpre), False
-        check(lib.mad_linear_bwd_input(_ptr(dy), _ptr(W), _ptr(xpre), _ptr(dx), rows, K, N, int(act_in), int(accumulate),
-                                       _stream()), "mad_linear_bwd_input")
+        nbytes = lib.mad_linear_bwd_input_workspace(rows, K, N)
+        ws = torch.empty((nbytes,), dtype=torch.uint8, device=dy.device)
+        check(lib.mad_linear_bwd_input(_ptr(dy), _ptr(W), _ptr(xpre), _ptr(dx), _ptr(ws), nbytes, rows, K, N, int(act_in),
+                                       int(accumulate), _stream()), "mad_linear_bwd_input")
     return dx, dW, db
 
 

@@ -27,10 +27,36 @@ from .model import DhariwalUNet
 from .unet_spec import GN_EPS, BlockSpec, gn_groups
 
 
-def _dgrad_weight(w: Tensor) -> Tensor:
+def allreduce_flat(flat: Tensor, bucket_elems: int, group=None) -> int:
+    """Sum ``flat`` over the ranks of ``group`` in place, as a few large asynchronous all-reduces over
+    contiguous ranges (RCCL on GPUs, gloo on CPU tensors); returns the number of collectives issued."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return 0
+    n = flat.numel()
+    works = [dist.all_reduce(flat[o:min(o + bucket_elems, n)], group=group, async_op=True)
+             for o in range(0, n, bucket_elems)]
+    for w in works:
+        w.wait()
+    return len(works)
+
+
+def warmup_lr(base_lr: float, optimizer_steps_done: int, warmup_steps: int) -> float:
+    """transformers ``get_constant_schedule_with_warmup`` (main.py:179-182): the k-th optimizer step (k from 0)
+    runs at base_lr * k / warmup while k < warmup."""
+    if warmup_steps > 0 and optimizer_steps_done < warmup_steps:
+        return base_lr * optimizer_steps_done / max(1, warmup_steps)
+    return base_lr
+
+
+def _dgrad_weight(e: dict, key: str) -> Tensor:
     """(Cout,k,k,Cin) forward pack -> (Cin,k,k,Cout) with the taps flipped: the forward conv kernels then
-    compute the data gradient, dx = conv(dy, w')."""
-    return w.flip(1, 2).permute(3, 1, 2, 0).contiguous()
+    compute the data gradient, dx = conv(dy, w').  Kept beside the forward pack (both are rebuilt after an
+    optimizer step)."""
+    tk = key + ".T"
+    if tk not in e:
+        e[tk] = e[key].flip(1, 2).permute(3, 1, 2, 0).contiguous()
+    return e[tk]
 
 
 class _Saved:
@@ -59,6 +85,8 @@ class UNetTrainer:
         self.step_count = 0
         self.seed = seed
         self._drop_calls = 0
+        self._accumulating = False
+        self.micro_batches = 0
         params = list(unet.named_parameters())
         if not params or not params[0][1].is_cuda:
             raise RuntimeError("UNetTrainer needs the model on the GPU (the training step has no CPU path)")
@@ -82,8 +110,19 @@ class UNetTrainer:
 
     # ------------------------------------------------------------------ helpers
     def _set(self, name: str, g: Tensor) -> None:
+        """Store (first micro-batch) or add (gradient accumulation) one parameter's gradient."""
         dst = self.grads[name]
-        dst.copy_(g.reshape(dst.shape))
+        if self._accumulating:
+            dst.add_(g.reshape(dst.shape))
+        else:
+            dst.copy_(g.reshape(dst.shape))
+
+    def _wgrad(self, name: str, x: Tensor, dy: Tensor, ksize: int, upsample: bool = False) -> None:
+        """Conv weight gradient written (or, when accumulating micro-batches, added) straight into the flat buffer."""
+        ops.conv_wgrad(x, dy, ksize, upsample=upsample, out=self.grads[name], accumulate=self._accumulating)
+
+    def _bgrad(self, name: str, dy: Tensor) -> None:
+        ops.bias_grad(dy, out=self.grads[name], accumulate=self._accumulating)
 
     @staticmethod
     def _conv3(x: Tensor, w: Tensor, b: Optional[Tensor], upsample: bool = False, residual: Optional[Tensor] = None,
@@ -215,26 +254,30 @@ class UNetTrainer:
         ada_v, dada_v = ada[:, e["ada_off"]:], dada[:, e["ada_off"]:]
         dy = dout
         if b.attention:
-            self._set(f"{n}.proj.weight", ops.conv_wgrad(sv.att, dout, 1))
-            self._set(f"{n}.proj.bias", ops.bias_grad(dout))
-            datt = ops.conv2d(dout, _dgrad_weight(e["proj.w"]), None)
+            self._wgrad(f"{n}.proj.weight", sv.att, dout, 1)
+            self._bgrad(f"{n}.proj.bias", dout)
+            datt = ops.conv2d(dout, _dgrad_weight(e, "proj.w"), None)
             dqkv = ops.attention_backward(sv.qkv, sv.att, datt, sv.lse, b.num_heads)
             # the packed qkv rows are a permutation of the reference's (model.py:359-363): undo it for the masters
             co, heads = b.out_channels, b.num_heads
             idx = torch.arange(3 * co, device=dout.device).reshape(heads, 64, 3).permute(0, 2, 1).reshape(-1)
             gw = ops.conv_wgrad(sv.hn, dqkv, 1)
             gb = ops.bias_grad(dqkv)
-            self.grads[f"{n}.qkv.weight"].index_copy_(0, idx, gw)
-            self.grads[f"{n}.qkv.bias"].index_copy_(0, idx, gb)
-            dhn = ops.conv2d(dqkv, _dgrad_weight(e["qkv.w"]), None)
+            if self._accumulating:
+                self.grads[f"{n}.qkv.weight"].index_add_(0, idx, gw)
+                self.grads[f"{n}.qkv.bias"].index_add_(0, idx, gb)
+            else:
+                self.grads[f"{n}.qkv.weight"].index_copy_(0, idx, gw)
+                self.grads[f"{n}.qkv.bias"].index_copy_(0, idx, gb)
+            dhn = ops.conv2d(dqkv, _dgrad_weight(e, "qkv.w"), None)
             dy, _, dg, db = ops.gn_backward(sv.y, dhn, sv.c2, sv.y_part, e["norm2.g"], e["norm2.b"],
                                             gn_groups(b.out_channels), GN_EPS, act=False, add1=dout)
             self._set(f"{n}.norm2.weight", dg)
             self._set(f"{n}.norm2.bias", db)
         # conv1 and the AdaGN in front of it
-        self._set(f"{n}.conv1.weight", ops.conv_wgrad(sv.h1, dy, 3))
-        self._set(f"{n}.conv1.bias", ops.bias_grad(dy))
-        dh1 = self._dgrad3(dy, _dgrad_weight(e["conv1.w"]))
+        self._wgrad(f"{n}.conv1.weight", sv.h1, dy, 3)
+        self._bgrad(f"{n}.conv1.bias", dy)
+        dh1 = self._dgrad3(dy, _dgrad_weight(e, "conv1.w"))
         if sv.seed is not None:
             ops.dropout_(dh1, sv.seed, self.dropout)
         dh, _, dg, db = ops.gn_backward(sv.h, dh1, sv.c1, sv.h_part, e["norm1.g"], e["norm1.b"],
@@ -243,16 +286,16 @@ class UNetTrainer:
         self._set(f"{n}.norm1.weight", dg)
         self._set(f"{n}.norm1.bias", db)
         # conv0 (input possibly resampled after norm0 + SiLU)
-        self._set(f"{n}.conv0.weight", ops.conv_wgrad(sv.h0, dh, 3, upsample=b.up))
-        self._set(f"{n}.conv0.bias", ops.bias_grad(dh))
-        dh0 = self._dgrad3(dh, _dgrad_weight(e["conv0.w"]))
+        self._wgrad(f"{n}.conv0.weight", sv.h0, dh, 3, upsample=b.up)
+        self._bgrad(f"{n}.conv0.bias", dh)
+        dh0 = self._dgrad3(dh, _dgrad_weight(e, "conv0.w"))
         mode0 = ops.GRAD_FROM_DOUBLE if b.up else (ops.GRAD_FROM_HALF if b.down else ops.GRAD_SAME)
         # the residual branch's gradient w.r.t. the block input
         if b.skip_conv:
             xin = sv.x if sv.skip is None else torch.cat([sv.x, sv.skip], dim=-1)
-            self._set(f"{n}.skip.weight", ops.conv_wgrad(xin, dy, 1))
-            self._set(f"{n}.skip.bias", ops.bias_grad(dy))
-            dres, res_mode = ops.conv2d(dy, _dgrad_weight(e["skip.w"]), None), ops.GRAD_SAME
+            self._wgrad(f"{n}.skip.weight", xin, dy, 1)
+            self._bgrad(f"{n}.skip.bias", dy)
+            dres, res_mode = ops.conv2d(dy, _dgrad_weight(e, "skip.w"), None), ops.GRAD_SAME
         else:
             dres, res_mode = dy, mode0
         add2 = None
@@ -341,24 +384,23 @@ class UNetTrainer:
         return 1 <= i <= n_enc
 
     # ------------------------------------------------------------------ step
-    def forward_backward(self, x_t: Tensor, t: Tensor, class_labels: Optional[Tensor], target: Tensor) -> Tensor:
+    def forward_backward(self, x_t: Tensor, t: Tensor, class_labels: Optional[Tensor], target: Tensor,
+                         accumulate: bool = False) -> Tensor:
+        """Loss of one micro-batch and its gradients; ``accumulate`` adds to the gradients already held
+        (``accelerator.accumulate``, main.py:239)."""
         self._drop_calls = 0
+        self._accumulating = bool(accumulate) and self.micro_batches > 0
         pred, tape = self.forward(x_t, t, class_labels)
         loss, dpred = ops.mse_loss_grad(pred, target.to(torch.float32))
         self.backward(tape, dpred)
+        self.micro_batches = self.micro_batches + 1 if accumulate else 1
+        self._accumulating = False
         return loss
 
     def sync_grads(self) -> None:
-        """Sum the gradients over the data-parallel ranks: a few large all-reduces over contiguous ranges
-        of the flat buffer (RCCL on GPUs); the division by the world size is folded into the update."""
-        import torch.distributed as dist
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(self.group) == 1:
-            return
-        n = self.gflat.numel()
-        works = [dist.all_reduce(self.gflat[o:min(o + self.bucket_elems, n)], group=self.group, async_op=True)
-                 for o in range(0, n, self.bucket_elems)]
-        for w in works:
-            w.wait()
+        """Sum the gradients over the data-parallel ranks; the division by the world size (and by the number
+        of accumulated micro-batches) is folded into the update."""
+        allreduce_flat(self.gflat, self.bucket_elems, self.group)
 
     def ema_decay(self) -> float:
         """diffusers ``EMAModel.get_decay`` with warm-up (main.py:153-159): 1 - (1 + step/inv_gamma)^-power."""
@@ -369,23 +411,33 @@ class UNetTrainer:
         return max(0.0, min(max_decay, 1.0 - (1.0 + step / inv_gamma) ** -power))
 
     def step(self, lr: Optional[float] = None, world_size: int = 1) -> None:
+        """nan_to_num + AdamW + EMA on the mean gradient over ranks and accumulated micro-batches."""
         self.step_count += 1
+        scale = 1.0 / (world_size * max(1, self.micro_batches))
         ops.adamw_step_(self.flat, self.gflat, self.m, self.v, self.ema, self.lr if lr is None else lr, self.betas[0],
-                        self.betas[1], self.eps, self.weight_decay, self.step_count, grad_scale=1.0 / world_size,
+                        self.betas[1], self.eps, self.weight_decay, self.step_count, grad_scale=scale,
                         ema_decay=self.ema_decay())
+        self.micro_batches = 0
         self.unet.invalidate()
 
     def train_step(self, x0: Tensor, class_labels: Optional[Tensor], alphas_cumprod: Tensor,
-                   generator: Optional[torch.Generator] = None, num_timesteps: int = 1000) -> Tensor:
-        """main.py:235-257 for one batch of clean images x0 (NCHW fp32 in [-1, 1])."""
+                   generator: Optional[torch.Generator] = None, num_timesteps: int = 1000, accumulation: int = 1,
+                   warmup_steps: int = 0) -> Tensor:
+        """main.py:235-257 for one optimizer step: ``accumulation`` micro-batches split from x0 (NCHW fp32 in
+        [-1, 1]), gradient all-reduce, update.  Returns the mean loss (device scalar)."""
         import torch.distributed as dist
-        B = x0.shape[0]
-        t = torch.randint(0, num_timesteps, (B,), device=x0.device, generator=generator)
-        noise = torch.randn(x0.shape, device=x0.device, dtype=torch.float32, generator=generator)
-        a = alphas_cumprod.to(x0.device)[t].to(torch.float32)
-        x_t = a.sqrt().view(B, 1, 1, 1) * x0 + (1.0 - a).sqrt().view(B, 1, 1, 1) * noise
-        loss = self.forward_backward(x_t, t.to(torch.float32), class_labels, noise)
+        alphas = alphas_cumprod.to(x0.device)
+        total = None
+        for xs, ls in zip(x0.chunk(accumulation), (class_labels.chunk(accumulation) if class_labels is not None
+                                                   else [None] * accumulation)):
+            B = xs.shape[0]
+            t = torch.randint(0, num_timesteps, (B,), device=x0.device, generator=generator)
+            noise = torch.randn(xs.shape, device=x0.device, dtype=torch.float32, generator=generator)
+            a = alphas[t].to(torch.float32)
+            x_t = a.sqrt().view(B, 1, 1, 1) * xs + (1.0 - a).sqrt().view(B, 1, 1, 1) * noise     # add_noise, main.py:237
+            loss = self.forward_backward(x_t, t.to(torch.float32), ls, noise, accumulate=True)
+            total = loss if total is None else total + loss
         self.sync_grads()
         ws = dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
-        self.step(world_size=ws)
-        return loss
+        self.step(lr=warmup_lr(self.lr, self.step_count, warmup_steps), world_size=ws)
+        return total / accumulation

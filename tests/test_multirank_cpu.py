@@ -45,3 +45,23 @@ def test_two_ranks_cover_the_list(tmp_path):
 
 def test_single_process_needs_no_group():
     assert job_throughput(8, 2.0) == (8, 2.0, 4.0)
+
+
+def _grad_worker(rank, world, port):
+    """The training step's only collective: the bucketed sum of the flat gradient buffer."""
+    from mad_amd.train import allreduce_flat, warmup_lr
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n = 1000
+    flat = torch.arange(n, dtype=torch.float32) * (rank + 1)
+    calls = allreduce_flat(flat, bucket_elems=300)                    # 4 ranges, the last one ragged
+    assert calls == 4
+    assert torch.equal(flat, torch.arange(n, dtype=torch.float32) * sum(r + 1 for r in range(world)))
+    assert warmup_lr(1e-4, 0, 1000) == 0.0 and warmup_lr(1e-4, 500, 1000) == 5e-5 and warmup_lr(1e-4, 1000, 1000) == 1e-4
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_two_ranks_sum_the_flat_gradient():
+    mp.spawn(_grad_worker, args=(2, _free_port()), nprocs=2, join=True)
