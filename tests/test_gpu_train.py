@@ -117,3 +117,34 @@ def test_training_reduces_loss(dev):
     assert min(losses[-5:]) < 0.8 * losses[0]
     assert torch.isfinite(tr.flat).all() and torch.isfinite(tr.ema).all()
     assert float((tr.ema - tr.flat).abs().max()) > 0
+
+
+def test_data_parallel_and_accumulated_steps_equal_the_big_batch(dev):
+    """What the all-reduce computes, done by hand (the collective itself is covered on gloo): two replicas on
+    half batches, gradients summed, update scaled by 1/world -- and the same through gradient accumulation --
+    both equal one step on the whole batch."""
+    from mad_amd.train import UNetTrainer
+    cfg, m, sd, x, t, lab, target = _setup("model_tiny.yaml", "fp32", dev, B=4)
+    x, t, lab, target = (v.to(dev) for v in (x, t, lab, target))
+
+    def fresh():
+        _, mm, *_ = _setup("model_tiny.yaml", "fp32", dev, B=4)
+        return UNetTrainer(mm.unet, lr=1e-3, dropout=0.0)
+
+    whole = fresh()
+    whole.forward_backward(x, t, lab, target)
+    whole.step()
+    r0, r1 = fresh(), fresh()
+    r0.forward_backward(x[:2], t[:2], lab[:2], target[:2])
+    r1.forward_backward(x[2:], t[2:], lab[2:], target[2:])
+    total = r0.gflat + r1.gflat                      # the all-reduce (sum)
+    r0.gflat.copy_(total)
+    r0.step(world_size=2)
+    assert rel_err(r0.flat.cpu(), whole.flat.cpu()) < 1e-5
+    acc = fresh()
+    acc.forward_backward(x[:2], t[:2], lab[:2], target[:2], accumulate=True)
+    acc.forward_backward(x[2:], t[2:], lab[2:], target[2:], accumulate=True)
+    assert acc.micro_batches == 2
+    acc.step()
+    assert rel_err(acc.flat.cpu(), whole.flat.cpu()) < 1e-5
+    assert rel_err(acc.ema.cpu(), whole.ema.cpu()) < 1e-5
