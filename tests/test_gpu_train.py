@@ -77,6 +77,31 @@ def test_train_gradients_match_autograd(dev, precision):
     assert worst[1] < tol, worst
 
 
+@pytest.mark.parametrize("cfg_file", ["model_64_64.yaml", "model_256_256.yaml"])
+def test_train_gradients_real_configs(dev, cfg_file):
+    """The real configurations, one image, bf16 activations: loss and per-tensor gradient direction against
+    fp32 autograd through the oracle (cosine similarity: bf16 rounding through ~40 blocks leaves a few per
+    cent of noise on individual elements)."""
+    from mad_amd.train import UNetTrainer
+    cfg, m, sd, x, t, lab, target = _setup(cfg_file, "bf16", dev, B=1)
+    want_loss, want_pred, want = _oracle_grads(cfg, sd, x, t, lab, target)
+    tr = UNetTrainer(m.unet, dropout=0.0)
+    loss = tr.forward_backward(x.to(dev), t.to(dev), lab.to(dev), target.to(dev))
+    assert abs(float(loss) - want_loss) < 3e-2 * want_loss
+    worst = ("", 1.0)
+    for k, g in want.items():
+        got = tr.grads[k].cpu().double().reshape(-1)
+        ref = g.double().reshape(-1)
+        assert torch.isfinite(got).all(), k
+        cos = float((got @ ref) / (got.norm() * ref.norm()).clamp_min(1e-30))
+        ratio = float(got.norm() / ref.norm().clamp_min(1e-30))
+        if cos < worst[1]:
+            worst = (k, cos)
+        assert 0.9 < ratio < 1.1, (k, ratio)
+    print(f"{cfg_file}: worst gradient cosine {worst[1]:.5f} at {worst[0]}")
+    assert worst[1] > 0.99, worst
+
+
 def test_adamw_ema_step_matches_torch(dev):
     """Flat fused update against torch.optim.AdamW (+ nan_to_num and the EMA rule) on random buffers."""
     from mad_amd import ops
