@@ -176,8 +176,14 @@ __global__ void wgrad_reduce_kernel(const float* partial, float* dst, size_t n, 
                                     int Cin) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    float s = 0.0f;
-    for (int k = 0; k < nsplit; ++k) s += partial[(size_t)k * n + i];
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+    int k = 0;
+    for (; k + 4 <= nsplit; k += 4) {
+        s0 += partial[(size_t)k * n + i]; s1 += partial[(size_t)(k + 1) * n + i];
+        s2 += partial[(size_t)(k + 2) * n + i]; s3 += partial[(size_t)(k + 3) * n + i];
+    }
+    for (; k < nsplit; ++k) s0 += partial[(size_t)k * n + i];
+    const float s = (s0 + s1) + (s2 + s3);
     dst[i] = accumulate ? dst[i] + s : s;
 }
 
@@ -368,7 +374,9 @@ extern "C" int mad_bias_grad(const void* dy, int dtype, long rows, int C, float*
     MAD_REQUIRE(rows > 0 && C > 0, "mad_bias_grad: bad shape");
     MAD_REQUIRE(workspace_bytes >= mad_bias_grad_workspace(C), "mad_bias_grad: workspace too small");
     hipStream_t s = (hipStream_t)stream;
-    const int splits = rows < 256 ? (int)rows : 256;
+    // enough row shares to fill the chip for long inputs, few for short ones (the second pass adds them serially)
+    long want = rows / 64;
+    const int splits = (int)(want < 1 ? 1 : (want > 256 ? 256 : want));
     const dim3 grid((C + 255) / 256, splits);
     if (dtype == MAD_BF16)
         hipLaunchKernelGGL((colsum_kernel<bf16_t>), grid, dim3(256), 0, s, (const bf16_t*)dy, (float*)workspace, rows, C,
