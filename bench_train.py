@@ -31,6 +31,9 @@ def parse_args():
     p.add_argument("--config", default=os.path.join(REPO, "configs", "model_256_256.yaml"))
     p.add_argument("--batch", type=int, default=0, help="images per GPU per micro-batch (0: TRAIN.BATCH_SIZE)")
     p.add_argument("--accum", type=int, default=0, help="micro-batches per optimizer step (0: the config's)")
+    p.add_argument("--split", default="fused", choices=["fused", "micro"],
+                   help="fused: the accum*batch images of one optimizer step run as ONE batch (same mean gradient; "
+                        "288 GB of HBM hold its activations); micro: accum separate micro-batches as the reference runs them")
     p.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     p.add_argument("--no-cpu-baseline", action="store_true")
     return p.parse_args()
@@ -99,9 +102,11 @@ def main():
     x0 = synthetic_faces(B * accum, R, seed=300 + rank).to(dev)
     labels = torch.eye(2, device=dev)[torch.arange(B * accum, device=dev) % 2]
 
+    passes = accum if args.split == "micro" else 1        # forward/backward passes per optimizer step
+
     def one_step():
         return tr.train_step(x0, labels, alphas, generator=gen, num_timesteps=int(cfg.TRAIN.TIME_STEPS),
-                             accumulation=accum, warmup_steps=int(cfg.TRAIN.LR_WARMUP))
+                             accumulation=passes, warmup_steps=int(cfg.TRAIN.LR_WARMUP))
 
     def barrier():
         if world > 1:
@@ -124,7 +129,8 @@ def main():
         elapsed = float(t.item())
     # one more (untimed) micro-batch with per-launch stream events on the MFMA kernels
     ops.TIMER.active = True
-    tr.forward_backward(x0[:B], torch.full((B,), 500.0, device=dev), labels[:B], torch.randn_like(x0[:B]))
+    Bp = B * accum // passes
+    tr.forward_backward(x0[:Bp], torch.full((Bp,), 500.0, device=dev), labels[:Bp], torch.randn_like(x0[:Bp]))
     ops.TIMER.active = False
     kern = ops.TIMER.summary()
 
@@ -141,17 +147,21 @@ def main():
             "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
-            "config": {"workload": f"{os.path.basename(args.config)} training step (main.py loop body): {accum} "
-                                   f"micro-batches of {B} images per GPU per optimizer step, dropout 0.1, epsilon "
-                                   f"prediction, MSE, AdamW(0.95, 0.999) + EMA, random-init (seeded) weights",
-                       "batch_per_gpu": B, "accumulation": accum, "resolution": R, "parallelism": f"dp{world}",
+            "config": {"workload": f"{os.path.basename(args.config)} training step (main.py loop body): {B * accum} images "
+                                   f"per GPU per optimizer step (the config's {accum} micro-batches of {B}), run as "
+                                   + (f"{accum} forward/backward passes of {B}" if passes > 1 else
+                                      f"one forward/backward pass of {B * accum} (same mean gradient)")
+                                   + ", dropout 0.1, epsilon prediction, MSE, AdamW(0.95, 0.999) + EMA, random-init "
+                                     "(seeded) weights",
+                       "batch_per_gpu": B, "accumulation": accum, "passes_per_step": passes, "resolution": R,
+                       "parallelism": f"dp{world}", "peak_hbm_gib": torch.cuda.max_memory_allocated(dev) / 2 ** 30,
                        "parameters": int(tr.flat.numel()), "gflop_per_image_forward": f_fwd / 1e9,
                        "final_loss": loss},
             "mfma_util_end_to_end": value * 3.0 * f_fwd / 1e12 / (PEAK_BF16_TFLOPS * world),
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_BF16_TFLOPS, "traffic": None, "kernel": dom,
                          "launches_timed": d["launches"], "avg_launch_ms": d["ms"] / d["launches"],
-                         "mfma_kernels": {k: {"tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12, "ms_per_micro_batch": v["ms"],
+                         "mfma_kernels": {k: {"tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12, "ms_per_pass": v["ms"],
                                               "launches": v["launches"]} for k, v in mfma.items()}},
         }
         if not args.no_cpu_baseline and world == 1:

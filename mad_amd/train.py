@@ -292,8 +292,16 @@ class UNetTrainer:
         mode0 = ops.GRAD_FROM_DOUBLE if b.up else (ops.GRAD_FROM_HALF if b.down else ops.GRAD_SAME)
         # the residual branch's gradient w.r.t. the block input
         if b.skip_conv:
-            xin = sv.x if sv.skip is None else torch.cat([sv.x, sv.skip], dim=-1)
-            self._wgrad(f"{n}.skip.weight", xin, dy, 1)
+            if sv.skip is None:
+                self._wgrad(f"{n}.skip.weight", sv.x, dy, 1)
+            else:                            # the projection's input is the concatenation: one gradient per source
+                gsk, c1 = self.grads[f"{n}.skip.weight"], sv.x.shape[3]
+                for sl, src in ((slice(0, c1), sv.x), (slice(c1, None), sv.skip)):
+                    g = ops.conv_wgrad(src, dy, 1)
+                    if self._accumulating:
+                        gsk[:, sl].add_(g)
+                    else:
+                        gsk[:, sl].copy_(g)
             self._bgrad(f"{n}.skip.bias", dy)
             dres, res_mode = ops.conv2d(dy, _dgrad_weight(e, "skip.w"), None), ops.GRAD_SAME
         else:
@@ -323,12 +331,16 @@ class UNetTrainer:
         dev = dpred.device
         # out_conv: weight gradient on the generic kernel, data gradient through the 3x3 kernel on a
         # channel-padded NHWC copy of dpred
-        self._set("out_conv.weight", ops.conv_wgrad_edge(tape["hact"], False, dpred, True, 3))
         self._set("out_conv.bias", dpred.sum((0, 2, 3)))
         Cf, Co = s.final_channels, s.out_channels
         pad_c = 32 if dt == torch.bfloat16 else 16
         dp = torch.zeros((B, dpred.shape[2], dpred.shape[3], pad_c), dtype=dt, device=dev)
         dp[..., :Co] = dpred.permute(0, 2, 3, 1).to(dt)
+        if dt == torch.bfloat16:
+            # the 3 image channels zero-padded to one 32-channel MFMA block: the general weight-gradient kernel
+            self._set("out_conv.weight", ops.conv_wgrad(tape["hact"], dp, 3)[:Co])
+        else:
+            self._set("out_conv.weight", ops.conv_wgrad_edge(tape["hact"], False, dpred, True, 3))
         wT = torch.zeros((Cf, 3, 3, pad_c), dtype=dt, device=dev)
         wT[..., :Co] = P["out.w"].flip(1, 2).permute(3, 1, 2, 0).to(dt)
         dhact = self._dgrad3(dp, wT)
@@ -356,7 +368,13 @@ class UNetTrainer:
         if pending:
             dh = dh + pending.pop(0)
         assert not pending, "unconsumed skip gradients"
-        self._set(f"{s.enc_conv_name}.weight", ops.conv_wgrad_edge(tape["x"], True, dh, False, 3))
+        if dt == torch.bfloat16:
+            xin = tape["x"]
+            xp = torch.zeros((B, xin.shape[2], xin.shape[3], 32), dtype=dt, device=dev)
+            xp[..., :xin.shape[1]] = xin.permute(0, 2, 3, 1).to(dt)
+            self._set(f"{s.enc_conv_name}.weight", ops.conv_wgrad(xp, dh, 3)[:, :xin.shape[1]])
+        else:
+            self._set(f"{s.enc_conv_name}.weight", ops.conv_wgrad_edge(tape["x"], True, dh, False, 3))
         self._set(f"{s.enc_conv_name}.bias", ops.bias_grad(dh))
 
         # embedding MLP: ada = aff(silu(pre2)), pre2 = lin1(silu(pre1)) + label(lab), pre1 = lin0(emb0)
