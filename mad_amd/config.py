@@ -91,12 +91,20 @@ def create_cfg() -> CfgNode:
     cfg.TRAIN.MAKEUP = None
     cfg.TRAIN.RESUME = None
     cfg.TRAIN.IMAGE_SIZE = 256
+    cfg.TRAIN.LOG_INTERVAL = 20
+    cfg.TRAIN.SAVE_INTERVAL = 10000
+    cfg.TRAIN.SAMPLE_INTERVAL = 10000
     cfg.TRAIN.ROOT = None
     cfg.TRAIN.TEXT_LABEL_PATH = None
     cfg.TRAIN.BATCH_SIZE = 2
+    cfg.TRAIN.NUM_WORKERS = 4
     cfg.TRAIN.MAX_ITER = 350000
     cfg.TRAIN.GRADIENT_ACCUMULATION_STEPS = 16
     cfg.TRAIN.MIXED_PRECISION = "no"
+    cfg.TRAIN.GRAD_NORM = 1.0
+    cfg.TRAIN.EMA_MAX_DECAY = 0.9999
+    cfg.TRAIN.EMA_INV_GAMMA = 1.0
+    cfg.TRAIN.EMA_POWER = 0.75
     cfg.TRAIN.LR = 0.0001
     cfg.TRAIN.LR_WARMUP = 1000
     cfg.TRAIN.TIME_STEPS = 1000

@@ -65,3 +65,36 @@ def test_generate_transfer_cli(tmp_path):
     assert sorted(os.listdir(out)) == ["pred_0.png", "pred_1.png"]
     img = np.array(Image.open(out / "pred_1.png"))
     assert img.shape == (16, 16, 3) and img.std() > 0
+
+
+def test_training_cli(tmp_path):
+    """main.py on synthetic images: iterations, checkpoint in the reference's format, resume, EMA sampling."""
+    import main as train_main
+    from mad_amd.checkpoint import load_checkpoint
+    from mad_amd.config import load_cfg
+    from mad_amd.model import build_model
+    proj = tmp_path / "run"
+    common = ["--config", os.path.join(REPO, "configs", "model_tiny.yaml"), "--synthetic", "16", "--opts",
+              "PROJECT_DIR", str(proj), "TRAIN.BATCH_SIZE", "2", "TRAIN.GRADIENT_ACCUMULATION_STEPS", "2",
+              "TRAIN.LOG_INTERVAL", "2", "TRAIN.SAVE_INTERVAL", "4", "TRAIN.SAMPLE_INTERVAL", "1000",
+              "TRAIN.LR_WARMUP", "2", "EVAL.SAMPLE_STEPS", "5"]
+    train_main.main(common + ["TRAIN.MAX_ITER", "6"])
+    ck = proj / "checkpoints"
+    assert sorted(os.listdir(ck)) == ["checkpoint_4.pth", "final.pth"]
+    assert os.path.exists(proj / "generate" / "iter_006.png")
+    st = torch.load(ck / "final.pth", map_location="cpu", weights_only=True)
+    assert set(st) == {"state_dict", "optimizer", "lr_scheduler", "iter", "ema_state_dict"} and st["iter"] == 5
+    cfg = load_cfg(os.path.join(REPO, "configs", "model_tiny.yaml"))
+    m = build_model(cfg)
+    assert len(st["ema_state_dict"]["shadow_params"]) == len(list(m.unet.parameters()))
+    assert load_checkpoint(m, str(ck / "final.pth"))["source"] == "ema_state_dict.shadow_params"
+    assert load_checkpoint(m, str(ck / "final.pth"), use_ema=False)["iter"] == 5
+    # resume from the intermediate checkpoint and finish; then sample only
+    train_main.main(common + ["TRAIN.MAX_ITER", "8", "TRAIN.RESUME", str(ck / "checkpoint_4.pth")])
+    st2 = torch.load(ck / "final.pth", map_location="cpu", weights_only=True)
+    assert st2["iter"] == 7 and st2["ema_state_dict"]["optimization_step"] == 4
+    out = tmp_path / "samples.png"
+    train_main.main(["--config", common[1], "--generate-only", "--save-file-name", str(out), "--opts", "PROJECT_DIR",
+                     str(proj), "TRAIN.RESUME", str(ck / "final.pth"), "EVAL.SAMPLE_STEPS", "5"])
+    from PIL import Image
+    assert np.array(Image.open(out)).shape == (16, 64, 3)        # EVAL.BATCH_SIZE = 4 images of 16x16 in one row
