@@ -36,6 +36,7 @@ def parse_args():
     p.add_argument("--workload", default="removal", choices=["removal", "transfer", "train"],
                    help="removal: domain_translation (headline); transfer: image_translation with inpainting and "
                         "per-step component masks, S = 180 (a secondary configuration, not the headline)")
+    p.add_argument("--graph", type=int, default=0, help="1: replay each denoiser evaluation as one captured HIP graph")
     p.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-evals", type=int, default=40, help="denoiser evaluations in the CPU sample")
@@ -158,20 +159,26 @@ def main():
     maps = torch.stack([synthetic_parsing_map(R, seed=rank * B + i) for i in range(B)]).to(dev)
 
     eval_count = [0]
-    inner = model.unet.forward
+    inner = model.forward
+    model.graph_replay = bool(args.graph)
 
     def counted(*a, **k):
-        # sample every n-th denoiser evaluation for per-kernel stream-event timing
-        ops.TIMER.active = timed[0] and (eval_count[0] % args.profile_every == 0)
-        sampled[0] += int(ops.TIMER.active)
+        # sample every n-th denoiser evaluation for per-kernel stream-event timing (launched one by one:
+        # events cannot bracket kernels inside a replayed graph)
+        sample = timed[0] and (eval_count[0] % args.profile_every == 0)
+        ops.TIMER.active = sample
+        sampled[0] += int(sample)
         eval_count[0] += 1
+        if sample:
+            model.graph_replay = False
         out = inner(*a, **k)
+        model.graph_replay = bool(args.graph)
         ops.TIMER.active = False
         return out
 
     timed = [False]
     sampled = [0]
-    model.unet.forward = counted
+    model.forward = counted
 
     guides = synthetic_faces(B, R, seed=900 + rank).to(dev) if args.workload == "transfer" else None
     if args.workload == "transfer":
