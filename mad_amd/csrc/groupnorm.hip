@@ -114,6 +114,8 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict
 }
 
 // ------------------------------------------------------------------------------- apply
+// grid (pixel shares, B), 256 threads.  A thread keeps ONE 16-byte channel chunk for all the (output) pixels
+// it visits, so its (a, d) pairs are read once into registers.
 template <typename T, bool POOL>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x1, int C1, const T* __restrict__ x2,
                                                         int C2, const float* __restrict__ coef, T* __restrict__ y,
@@ -121,13 +123,15 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x1,
     constexpr int VEC = Elem<T>::VEC;
     const int C = C1 + C2;
     const int cpr = C / VEC;
-    const int Ho = POOL ? H / 2 : H, Wo = POOL ? W / 2 : W;
-    const size_t total = (size_t)B * Ho * Wo * cpr;
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
-        const int chunk = (int)(idx % cpr);
-        const size_t opix = idx / cpr;                      // b*Ho*Wo + oy*Wo + ox
-        const int b = (int)(opix / ((size_t)Ho * Wo));
+    const int Ho = POOL ? H / 2 : H, Wo = POOL ? W / 2 : W, HWo = Ho * Wo;
+    const int b = blockIdx.y;
+    const int per = (HWo + gridDim.x - 1) / gridDim.x;
+    const int p0 = blockIdx.x * per, p1 = p0 + per < HWo ? p0 + per : HWo;
+    const int rows = cpr >= 256 ? 1 : 256 / cpr;
+    for (int cbase = 0; cbase < cpr; cbase += 256) {
+        const int chunk = cbase + (cpr >= 256 ? (int)threadIdx.x : (int)threadIdx.x % cpr);
+        const int row = cpr >= 256 ? 0 : (int)threadIdx.x / cpr;
+        if (chunk >= cpr || row >= rows) continue;
         const int c = chunk * VEC;
         const T* src;
         int cs, coff;
@@ -139,43 +143,44 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x1,
             const float4 v = *reinterpret_cast<const float4*>(cf + 2 * i);
             a[i] = v.x; d[i] = v.y; a[i + 1] = v.z; d[i + 1] = v.w;
         }
-        float r[VEC];
-        if (!POOL) {
-            Vec16<T> v;
-            v.load(src + opix * cs + coff);
-            float f[VEC];
-            v.unpack(f);
+        for (int p = p0 + row; p < p1; p += rows) {
+            float r[VEC];
+            if (!POOL) {
+                Vec16<T> v;
+                v.load(src + ((size_t)b * HWo + p) * cs + coff);
+                float f[VEC];
+                v.unpack(f);
 #pragma unroll
-            for (int i = 0; i < VEC; ++i) {
-                const float t = fmaf(f[i], a[i], d[i]);
-                r[i] = act ? silu_f(t) : t;
-            }
-        } else {
-            const int rem = (int)(opix % ((size_t)Ho * Wo));
-            const int oy = rem / Wo, ox = rem % Wo;
-#pragma unroll
-            for (int i = 0; i < VEC; ++i) r[i] = 0.0f;
-#pragma unroll
-            for (int dy = 0; dy < 2; ++dy)
-#pragma unroll
-                for (int dx = 0; dx < 2; ++dx) {
-                    const size_t ip = ((size_t)b * H + (2 * oy + dy)) * W + (2 * ox + dx);
-                    Vec16<T> v;
-                    v.load(src + ip * cs + coff);
-                    float f[VEC];
-                    v.unpack(f);
-#pragma unroll
-                    for (int i = 0; i < VEC; ++i) {
-                        const float t = fmaf(f[i], a[i], d[i]);
-                        r[i] += act ? silu_f(t) : t;
-                    }
+                for (int i = 0; i < VEC; ++i) {
+                    const float t = fmaf(f[i], a[i], d[i]);
+                    r[i] = act ? silu_f(t) : t;
                 }
+            } else {
+                const int oy = p / Wo, ox = p - oy * Wo;
 #pragma unroll
-            for (int i = 0; i < VEC; ++i) r[i] *= 0.25f;
+                for (int i = 0; i < VEC; ++i) r[i] = 0.0f;
+#pragma unroll
+                for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 2; ++dx) {
+                        const size_t ip = ((size_t)b * H + (2 * oy + dy)) * W + (2 * ox + dx);
+                        Vec16<T> v;
+                        v.load(src + ip * cs + coff);
+                        float f[VEC];
+                        v.unpack(f);
+#pragma unroll
+                        for (int i = 0; i < VEC; ++i) {
+                            const float t = fmaf(f[i], a[i], d[i]);
+                            r[i] += act ? silu_f(t) : t;
+                        }
+                    }
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) r[i] *= 0.25f;
+            }
+            Vec16<T> o;
+            o.pack(r);
+            o.store(y + ((size_t)b * HWo + p) * C + c);
         }
-        Vec16<T> o;
-        o.pack(r);
-        o.store(y + opix * C + c);
     }
 }
 
@@ -227,10 +232,12 @@ extern "C" int mad_gn_apply(const void* x1, int C1, const void* x2, int C2, cons
     MAD_REQUIRE(C1 > 0 && C1 % VEC == 0 && C2 >= 0 && C2 % VEC == 0 && (C2 == 0 || x2),
                 "mad_gn_apply: channels must be multiples of %d (C1=%d C2=%d)", VEC, C1, C2);
     MAD_REQUIRE(B > 0 && H > 0 && W > 0 && (!pool || (H % 2 == 0 && W % 2 == 0)), "mad_gn_apply: bad shape");
-    const size_t total = (size_t)B * (pool ? H / 2 : H) * (pool ? W / 2 : W) * ((C1 + C2) / VEC);
-    size_t g = (total + 255) / 256;
-    if (g > 4096) g = 4096;
-    dim3 grid((unsigned)g);
+    // pixel shares: about 2048 workgroups in all, at least 64 output pixels each
+    const int hwo = (pool ? H / 2 : H) * (pool ? W / 2 : W);
+    int shares = (2048 + B - 1) / B;
+    if (shares > (hwo + 63) / 64) shares = (hwo + 63) / 64;
+    if (shares < 1) shares = 1;
+    dim3 grid(shares, B);
 #define LAUNCH(T, P)                                                                                              \
     hipLaunchKernelGGL((gn_apply_kernel<T, P>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)x1, C1,        \
                        (const T*)x2, C2, coef, (T*)y, B, H, W, act)

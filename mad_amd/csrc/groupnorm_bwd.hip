@@ -187,47 +187,60 @@ struct GnBwdApplyArgs {
     int add1_mode, add2_mode;
 };
 
+// grid (pixel shares, B), 256 threads.  As in the partial-sum kernel a thread keeps ONE 16-byte channel chunk
+// for all the pixels it visits, so the five per-channel coefficients (a, d, p, q, r) are read once into
+// registers instead of once per element.
 template <typename T>
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(GnBwdApplyArgs a) {
     constexpr int VEC = Elem<T>::VEC;
     const GnBwdArgs& s = a.g;
-    const int C = s.C1 + s.C2, cpr = C / VEC;
-    const size_t total = (size_t)s.B * s.H * s.W * cpr;
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
-        const int chunk = (int)(idx % cpr);
-        const size_t pix = idx / cpr;
-        const int b = (int)(pix / ((size_t)s.H * s.W));
-        const int rem = (int)(pix - (size_t)b * s.H * s.W);
-        const int y = rem / s.W, x = rem - y * s.W;
+    const int C = s.C1 + s.C2, cpr = C / VEC, HW = s.H * s.W;
+    const int b = blockIdx.y;
+    const int per = (HW + gridDim.x - 1) / gridDim.x;
+    const int p0 = blockIdx.x * per, p1 = p0 + per < HW ? p0 + per : HW;
+    const int rows = cpr >= 256 ? 1 : 256 / cpr;
+    for (int cbase = 0; cbase < cpr; cbase += 256) {
+        const int chunk = cbase + (cpr >= 256 ? (int)threadIdx.x : (int)threadIdx.x % cpr);
+        const int row = cpr >= 256 ? 0 : (int)threadIdx.x / cpr;
+        if (chunk >= cpr || row >= rows) continue;
         const int c = chunk * VEC;
         const T* src; T* dst; int cs, coff;
         if (c < s.C1) { src = (const T*)s.x1; dst = (T*)a.dx1; cs = s.C1; coff = c; }
         else { src = (const T*)s.x2; dst = (T*)a.dx2; cs = s.C2; coff = c - s.C1; }
-        Vec16<T> v; v.load(src + pix * cs + coff);
-        float f[VEC], g[VEC], r[VEC]; v.unpack(f);
-        load_grad<T>((const T*)s.dy, s.dy_mode, b, y, x, s.H, s.W, C, c, g);
+        float ca[VEC], cd[VEC], kp[VEC], kq[VEC], kr[VEC];
         const float* cf = s.coef + ((size_t)b * C + c) * 2;
         const float* bc = a.bcoef + ((size_t)b * C + c) * 4;
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
-            const float gi = s.act ? g[i] * silu_grad_f(fmaf(f[i], cf[2 * i], cf[2 * i + 1])) : g[i];
+            ca[i] = cf[2 * i]; cd[i] = cf[2 * i + 1];
             const float4 k = *reinterpret_cast<const float4*>(bc + 4 * i);
-            r[i] = fmaf(gi, k.x, fmaf(f[i], k.y, k.z));
+            kp[i] = k.x; kq[i] = k.y; kr[i] = k.z;
         }
-        // the other gradients arriving at x span the whole (concatenated) channel axis, like dy
-        if (a.add1) {
-            float t[VEC]; load_grad<T>((const T*)a.add1, a.add1_mode, b, y, x, s.H, s.W, C, c, t);
+        for (int p = p0 + row; p < p1; p += rows) {
+            const size_t pix = (size_t)b * HW + p;
+            const int y = p / s.W, x = p - y * s.W;
+            Vec16<T> v; v.load(src + pix * cs + coff);
+            float f[VEC], g[VEC], r[VEC]; v.unpack(f);
+            load_grad<T>((const T*)s.dy, s.dy_mode, b, y, x, s.H, s.W, C, c, g);
 #pragma unroll
-            for (int i = 0; i < VEC; ++i) r[i] += t[i];
-        }
-        if (a.add2) {
-            float t[VEC]; load_grad<T>((const T*)a.add2, a.add2_mode, b, y, x, s.H, s.W, C, c, t);
+            for (int i = 0; i < VEC; ++i) {
+                const float gi = s.act ? g[i] * silu_grad_f(fmaf(f[i], ca[i], cd[i])) : g[i];
+                r[i] = fmaf(gi, kp[i], fmaf(f[i], kq[i], kr[i]));
+            }
+            // the other gradients arriving at x span the whole (concatenated) channel axis, like dy
+            if (a.add1) {
+                float t[VEC]; load_grad<T>((const T*)a.add1, a.add1_mode, b, y, x, s.H, s.W, C, c, t);
 #pragma unroll
-            for (int i = 0; i < VEC; ++i) r[i] += t[i];
+                for (int i = 0; i < VEC; ++i) r[i] += t[i];
+            }
+            if (a.add2) {
+                float t[VEC]; load_grad<T>((const T*)a.add2, a.add2_mode, b, y, x, s.H, s.W, C, c, t);
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) r[i] += t[i];
+            }
+            Vec16<T> o; o.pack(r);
+            o.store(dst + pix * cs + coff);
         }
-        Vec16<T> o; o.pack(r);
-        o.store(dst + pix * cs + coff);
     }
 }
 
@@ -299,10 +312,13 @@ extern "C" int mad_gn_bwd_apply(const void* x1, int C1, const void* x2, int C2, 
     a.bcoef = bcoef; a.add1 = add1; a.add2 = add2; a.dx1 = dx1; a.dx2 = C2 ? dx2 : dx1;
     a.add1_mode = add1_mode; a.add2_mode = add2_mode;
     const int VEC = dtype == MAD_BF16 ? 8 : 4;
-    const size_t total = (size_t)B * H * W * ((C1 + C2) / VEC);
-    size_t g = (total + 255) / 256;
-    if (g > 4096) g = 4096;
-    if (dtype == MAD_BF16) hipLaunchKernelGGL(gn_bwd_apply_kernel<bf16_t>, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(gn_bwd_apply_kernel<float>, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, a);
+    // pixel shares: about 2048 workgroups in all, at least 64 pixels each
+    int shares = (2048 + B - 1) / B;
+    if (shares > (H * W + 63) / 64) shares = (H * W + 63) / 64;
+    if (shares < 1) shares = 1;
+    (void)VEC;
+    const dim3 grid(shares, B);
+    if (dtype == MAD_BF16) hipLaunchKernelGGL(gn_bwd_apply_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(gn_bwd_apply_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, a);
     return check_launch("mad_gn_bwd_apply");
 }
