@@ -211,6 +211,14 @@ int mad_gn_finalize(const float* partial1, int C1, int nsplit1, const float* par
 int mad_gn_apply(const void* x1, int C1, const void* x2, int C2, const float* coef, void* y,
                  int dtype, int B, int H, int W, int act, int pool, void* stream);
 
+/* mad_gn_apply (no pooling) followed by dropout of the result, in one pass: element e of y (its linear index)
+ * is kept with probability 1-p and scaled by 1/(1-p), decided by a counter hash of (seed, e) -- the mask
+ * mad_dropout and the mad_gn_bwd_* kernels rebuild from the same seed.
+ * silu(norm1(...)) followed by F.dropout in UNetBlock.forward (model.py:346-352). */
+int mad_gn_apply_dropout(const void* x1, int C1, const void* x2, int C2, const float* coef, void* y,
+                         int dtype, int B, int H, int W, int act, unsigned long long seed, float p,
+                         void* stream);
+
 /* Self-attention over L = H*W positions, head_dim 64: qkv is NHWC (B,L,3*C) with channel
  * head*192 + {0..63 q, 64..127 k, 128..191 v}; out is (B,L,C) with channel head*64 + d.
  * softmax(q.k/8) in fp32.  Replaces model.py:357-375 / AttentionOp (model.py:199-212). */
@@ -251,16 +259,19 @@ int mad_bias_grad(const void* dy, int dtype, long rows, int C, float* dbias, voi
  *             like ada: dada[b*ada_stride + c] = dscale, [.. + C + c] = dshift
  *   apply:    dx = g*p + x*q + r (+ add1 + add2, gradients reaching x by other branches, C1+C2 channels,
  *             each with its own resolution mode), written as dx1 (B,H,W,C1) and dx2 (B,H,W,C2).
+ * drop_seed / drop_p: the dropout mad_gn_apply_dropout applied to h in the forward (p = 0: none); dy is then
+ * masked and scaled the same way before anything else (dy_mode 0 only).
  * Autograd of GroupNorm.forward + silu + addcmul (model.py:182-190, 341-348). */
 int mad_gn_bwd_partial(const void* x1, int C1, const void* x2, int C2, const void* dy, int dy_mode,
-                       const float* coef, int act, int dtype, float* gsum, int B, int H, int W,
-                       int nsplit, void* stream);
+                       const float* coef, int act, unsigned long long drop_seed, float drop_p, int dtype,
+                       float* gsum, int B, int H, int W, int nsplit, void* stream);
 int mad_gn_bwd_finalize(const float* stat1, int C1, int nsplit1, const float* stat2, int C2, int nsplit2,
                         const float* gsum, int nsplit_g, const float* gamma, const float* beta,
                         const float* ada, int ada_stride, float* bcoef, float* dgb, float* dada, int B,
                         int groups, int HW, float eps, void* stream);
 int mad_gn_bwd_apply(const void* x1, int C1, const void* x2, int C2, const void* dy, int dy_mode,
-                     const float* coef, int act, const float* bcoef, const void* add1, int add1_mode,
+                     const float* coef, int act, unsigned long long drop_seed, float drop_p,
+                     const float* bcoef, const void* add1, int add1_mode,
                      const void* add2, int add2_mode, void* dx1, void* dx2, int dtype, int B, int H,
                      int W, void* stream);
 

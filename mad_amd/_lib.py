@@ -58,12 +58,15 @@ SIGNATURES = {
     "mad_conv_wgrad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_size_t] + [c_int] * 9 + [c_void_p]),
     "mad_bias_grad_workspace": (ctypes.c_size_t, [c_int]),
     "mad_bias_grad": (c_int, [c_void_p, c_int, ctypes.c_long, c_int, c_void_p, c_void_p, ctypes.c_size_t, c_int, c_void_p]),
-    "mad_gn_bwd_partial": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p] +
-                           [c_int] * 4 + [c_void_p]),
+    "mad_gn_bwd_partial": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, ctypes.c_ulonglong,
+                                   c_float, c_int, c_void_p] + [c_int] * 4 + [c_void_p]),
+    "mad_gn_apply_dropout": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p] + [c_int] * 5 +
+                             [ctypes.c_ulonglong, c_float, c_void_p]),
     "mad_gn_bwd_finalize": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p,
                                     c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p]),
-    "mad_gn_bwd_apply": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p,
-                                 c_int, c_void_p, c_int, c_void_p, c_void_p] + [c_int] * 4 + [c_void_p]),
+    "mad_gn_bwd_apply": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, ctypes.c_ulonglong,
+                                 c_float, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p] + [c_int] * 4 +
+                         [c_void_p]),
     "mad_conv_wgrad_edge_workspace": (ctypes.c_size_t, [c_int] * 6),
     "mad_conv_wgrad_edge": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, ctypes.c_size_t] +
                             [c_int] * 7 + [c_void_p]),

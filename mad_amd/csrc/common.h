@@ -70,4 +70,26 @@ template <typename T> struct Vec16 {
 // x * sigmoid(x); v_exp_f32 and v_rcp_f32 (1 ulp each)
 __device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 
+// Dropout keep-mask from a counter hash: element e of the tensor dropped with `seed` is kept with probability
+// 1-p and scaled by 1/(1-p).  The same (seed, e) gives the same decision in the forward and in the backward.
+__host__ __device__ __forceinline__ unsigned mix32(unsigned x) {
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+struct DropMask {
+    unsigned s0, s1, thr;      // thr == 0: no dropout
+    float scale;
+};
+inline DropMask make_drop_mask(unsigned long long seed, float p) {
+    DropMask m;
+    m.s0 = mix32((unsigned)seed); m.s1 = mix32((unsigned)(seed >> 32) ^ 0x9e3779b9u);
+    m.thr = p > 0.0f ? (unsigned)((double)p * 4294967296.0) : 0u;
+    m.scale = p > 0.0f ? 1.0f / (1.0f - p) : 1.0f;
+    return m;
+}
+__device__ __forceinline__ float drop_factor(const DropMask& m, unsigned long long e) {
+    const unsigned h = mix32(mix32((unsigned)e ^ m.s0) + (unsigned)(e >> 32) + m.s1);
+    return h >= m.thr ? m.scale : 0.0f;
+}
+
 }  // namespace mad

@@ -119,7 +119,7 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict
 template <typename T, bool POOL>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x1, int C1, const T* __restrict__ x2,
                                                         int C2, const float* __restrict__ coef, T* __restrict__ y,
-                                                        int B, int H, int W, int act) {
+                                                        int B, int H, int W, int act, DropMask dm) {
     constexpr int VEC = Elem<T>::VEC;
     const int C = C1 + C2;
     const int cpr = C / VEC;
@@ -177,6 +177,11 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x1,
 #pragma unroll
                 for (int i = 0; i < VEC; ++i) r[i] *= 0.25f;
             }
+            if (dm.thr) {                                   // dropout of the output element (its linear index in y)
+                const unsigned long long e0 = ((unsigned long long)b * HWo + p) * C + c;
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) r[i] *= drop_factor(dm, e0 + i);
+            }
             Vec16<T> o;
             o.pack(r);
             o.store(y + ((size_t)b * HWo + p) * C + c);
@@ -224,8 +229,8 @@ extern "C" int mad_gn_finalize(const float* partial1, int C1, int nsplit1, const
     return check_launch("mad_gn_finalize");
 }
 
-extern "C" int mad_gn_apply(const void* x1, int C1, const void* x2, int C2, const float* coef, void* y, int dtype,
-                            int B, int H, int W, int act, int pool, void* stream) {
+static int gn_apply_impl(const void* x1, int C1, const void* x2, int C2, const float* coef, void* y, int dtype,
+                         int B, int H, int W, int act, int pool, DropMask dm, void* stream) {
     MAD_REQUIRE(x1 && coef && y, "mad_gn_apply: null pointer");
     MAD_REQUIRE(dtype == MAD_BF16 || dtype == MAD_F32, "mad_gn_apply: bad dtype %d", dtype);
     const int VEC = dtype == MAD_BF16 ? 8 : 4;
@@ -240,9 +245,21 @@ extern "C" int mad_gn_apply(const void* x1, int C1, const void* x2, int C2, cons
     dim3 grid(shares, B);
 #define LAUNCH(T, P)                                                                                              \
     hipLaunchKernelGGL((gn_apply_kernel<T, P>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)x1, C1,        \
-                       (const T*)x2, C2, coef, (T*)y, B, H, W, act)
+                       (const T*)x2, C2, coef, (T*)y, B, H, W, act, dm)
     if (dtype == MAD_BF16) { if (pool) LAUNCH(bf16_t, true); else LAUNCH(bf16_t, false); }
     else { if (pool) LAUNCH(float, true); else LAUNCH(float, false); }
 #undef LAUNCH
     return check_launch("mad_gn_apply");
+}
+
+extern "C" int mad_gn_apply(const void* x1, int C1, const void* x2, int C2, const float* coef, void* y, int dtype,
+                            int B, int H, int W, int act, int pool, void* stream) {
+    return gn_apply_impl(x1, C1, x2, C2, coef, y, dtype, B, H, W, act, pool, make_drop_mask(0, 0.0f), stream);
+}
+
+extern "C" int mad_gn_apply_dropout(const void* x1, int C1, const void* x2, int C2, const float* coef, void* y,
+                                    int dtype, int B, int H, int W, int act, unsigned long long seed, float p,
+                                    void* stream) {
+    MAD_REQUIRE(p >= 0.0f && p < 1.0f, "mad_gn_apply_dropout: p=%f out of [0,1)", (double)p);
+    return gn_apply_impl(x1, C1, x2, C2, coef, y, dtype, B, H, W, act, 0, make_drop_mask(seed, p), stream);
 }

@@ -52,6 +52,7 @@ __device__ __forceinline__ float silu_grad_f(float u) {
 struct GnBwdArgs {
     const void* x1; const void* x2; const void* dy; const float* coef;
     int C1, C2, B, H, W, act, dy_mode;
+    DropMask dm;               // dropout that was applied to the forward's output (dy_mode 0 only); thr == 0: none
 };
 
 // ------------------------------------------------------------------------------- partial sums
@@ -88,6 +89,11 @@ __global__ __launch_bounds__(256) void gn_bwd_partial_kernel(GnBwdArgs a, float*
                 Vec16<T> v; v.load(src + (size_t)p * cs);
                 float f[VEC], g[VEC]; v.unpack(f);
                 load_grad<T>((const T*)a.dy, a.dy_mode, b, p / a.W, p % a.W, a.H, a.W, C, c, g);
+                if (a.dm.thr) {
+                    const unsigned long long e0 = ((unsigned long long)b * HW + p) * C + c;
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) g[i] *= drop_factor(a.dm, e0 + i);
+                }
 #pragma unroll
                 for (int i = 0; i < VEC; ++i) {
                     const float gi = a.act ? g[i] * silu_grad_f(fmaf(f[i], ca[i], cd[i])) : g[i];
@@ -222,6 +228,11 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(GnBwdApplyArgs a) {
             Vec16<T> v; v.load(src + pix * cs + coff);
             float f[VEC], g[VEC], r[VEC]; v.unpack(f);
             load_grad<T>((const T*)s.dy, s.dy_mode, b, y, x, s.H, s.W, C, c, g);
+            if (s.dm.thr) {
+                const unsigned long long e0 = (unsigned long long)pix * C + c;
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) g[i] *= drop_factor(s.dm, e0 + i);
+            }
 #pragma unroll
             for (int i = 0; i < VEC; ++i) {
                 const float gi = s.act ? g[i] * silu_grad_f(fmaf(f[i], ca[i], cd[i])) : g[i];
@@ -262,14 +273,16 @@ static int gn_bwd_check(const char* who, const void* x1, int C1, const void* x2,
 }
 
 extern "C" int mad_gn_bwd_partial(const void* x1, int C1, const void* x2, int C2, const void* dy, int dy_mode,
-                                  const float* coef, int act, int dtype, float* gsum, int B, int H, int W, int nsplit,
-                                  void* stream) {
+                                  const float* coef, int act, unsigned long long drop_seed, float drop_p, int dtype,
+                                  float* gsum, int B, int H, int W, int nsplit, void* stream) {
+    MAD_REQUIRE(drop_p >= 0.0f && drop_p < 1.0f && (drop_p == 0.0f || dy_mode == 0),
+                "mad_gn_bwd_partial: dropout needs p in [0,1) and a gradient at the same resolution");
     if (int rc = gn_bwd_check("mad_gn_bwd_partial", x1, C1, x2, C2, dy, coef, dtype, B, H, W, dy_mode)) return rc;
     MAD_REQUIRE(gsum && nsplit > 0 && (H * W) % nsplit == 0, "mad_gn_bwd_partial: HW=%d not divisible by nsplit=%d",
                 H * W, nsplit);
     GnBwdArgs a;
     a.x1 = x1; a.x2 = C2 ? x2 : x1; a.dy = dy; a.coef = coef; a.C1 = C1; a.C2 = C2; a.B = B; a.H = H; a.W = W;
-    a.act = act; a.dy_mode = dy_mode;
+    a.act = act; a.dy_mode = dy_mode; a.dm = make_drop_mask(drop_seed, drop_p);
     const int VEC = dtype == MAD_BF16 ? 8 : 4;
     const int cpr = (C1 + C2) / VEC;
     const int rows = cpr >= 256 ? 1 : 256 / cpr;
@@ -300,15 +313,18 @@ extern "C" int mad_gn_bwd_finalize(const float* stat1, int C1, int nsplit1, cons
 }
 
 extern "C" int mad_gn_bwd_apply(const void* x1, int C1, const void* x2, int C2, const void* dy, int dy_mode,
-                                const float* coef, int act, const float* bcoef, const void* add1, int add1_mode,
+                                const float* coef, int act, unsigned long long drop_seed, float drop_p,
+                                const float* bcoef, const void* add1, int add1_mode,
                                 const void* add2, int add2_mode, void* dx1, void* dx2, int dtype, int B, int H, int W,
                                 void* stream) {
     if (int rc = gn_bwd_check("mad_gn_bwd_apply", x1, C1, x2, C2, dy, coef, dtype, B, H, W, dy_mode)) return rc;
     MAD_REQUIRE(bcoef && dx1 && (C2 == 0 || dx2), "mad_gn_bwd_apply: null pointer");
     MAD_REQUIRE(add1_mode >= 0 && add1_mode <= 2 && add2_mode >= 0 && add2_mode <= 2, "mad_gn_bwd_apply: bad add mode");
+    MAD_REQUIRE(drop_p >= 0.0f && drop_p < 1.0f && (drop_p == 0.0f || dy_mode == 0),
+                "mad_gn_bwd_apply: dropout needs p in [0,1) and a gradient at the same resolution");
     GnBwdApplyArgs a;
     a.g.x1 = x1; a.g.x2 = C2 ? x2 : x1; a.g.dy = dy; a.g.coef = coef; a.g.C1 = C1; a.g.C2 = C2; a.g.B = B; a.g.H = H;
-    a.g.W = W; a.g.act = act; a.g.dy_mode = dy_mode;
+    a.g.W = W; a.g.act = act; a.g.dy_mode = dy_mode; a.g.dm = make_drop_mask(drop_seed, drop_p);
     a.bcoef = bcoef; a.add1 = add1; a.add2 = add2; a.dx1 = dx1; a.dx2 = C2 ? dx2 : dx1;
     a.add1_mode = add1_mode; a.add2_mode = add2_mode;
     const int VEC = dtype == MAD_BF16 ? 8 : 4;

@@ -55,27 +55,14 @@ __global__ __launch_bounds__(256) void linear_dw_kernel(const float* __restrict_
     dw[(size_t)n * K + k] = s;
 }
 
-// keep-mask from a counter hash: element i of call `seed` is kept with probability 1-p and scaled by 1/(1-p)
-__device__ __forceinline__ unsigned mix32(unsigned x) {
-    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
-    return x;
-}
-
 template <typename T>
-__global__ __launch_bounds__(256) void dropout_kernel(const T* __restrict__ x, T* __restrict__ y, size_t nvec,
-                                                       unsigned long long seed, float p, float scale) {
+__global__ __launch_bounds__(256) void dropout_kernel(const T* __restrict__ x, T* __restrict__ y, size_t nvec, DropMask m) {
     constexpr int VEC = Elem<T>::VEC;
-    const unsigned thr = (unsigned)(p * 4294967296.0);
-    const unsigned s0 = mix32((unsigned)seed), s1 = mix32((unsigned)(seed >> 32) ^ 0x9e3779b9u);
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (size_t)gridDim.x * 256) {
         Vec16<T> v; v.load(x + i * VEC);
         float f[VEC]; v.unpack(f);
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) {
-            const unsigned long long e = i * VEC + j;
-            const unsigned h = mix32(mix32((unsigned)e ^ s0) + (unsigned)(e >> 32) + s1);
-            f[j] = h >= thr ? f[j] * scale : 0.0f;
-        }
+        for (int j = 0; j < VEC; ++j) f[j] *= drop_factor(m, i * VEC + j);
         v.pack(f);
         v.store(y + i * VEC);
     }
@@ -171,13 +158,13 @@ extern "C" int mad_dropout(const void* x, void* y, int dtype, size_t n, unsigned
     if (nvec == 0) return 0;
     size_t g = (nvec + 255) / 256;
     if (g > 8192) g = 8192;
-    const float scale = 1.0f / (1.0f - p);
+    const DropMask m = make_drop_mask(seed, p);
     if (dtype == MAD_BF16)
         hipLaunchKernelGGL(dropout_kernel<bf16_t>, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
-                           (bf16_t*)y, nvec, seed, p, scale);
+                           (bf16_t*)y, nvec, m);
     else
         hipLaunchKernelGGL(dropout_kernel<float>, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, (const float*)x,
-                           (float*)y, nvec, seed, p, scale);
+                           (float*)y, nvec, m);
     return check_launch("mad_dropout");
 }
 

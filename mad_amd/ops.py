@@ -506,11 +506,13 @@ def gn_backward(x1: Tensor, dy: Tensor, coef: Tensor, stat1: Tensor, gamma: Tens
                 eps: float, act: bool, x2: Optional[Tensor] = None, stat2: Optional[Tensor] = None,
                 ada: Optional[Tensor] = None, ada_stride: int = 0, dada: Optional[Tensor] = None,
                 dy_mode: int = GRAD_SAME, add1: Optional[Tensor] = None, add1_mode: int = GRAD_SAME,
-                add2: Optional[Tensor] = None, add2_mode: int = GRAD_SAME, need_dx: bool = True):
+                add2: Optional[Tensor] = None, add2_mode: int = GRAD_SAME, need_dx: bool = True,
+                drop_seed: int = 0, drop_p: float = 0.0):
     """Backward of h = act(GroupNorm([x1, x2]) * (1 + scale) + shift).
 
     ``coef`` and ``stat1``/``stat2`` are the forward's (a, d) table and statistics partials; ``dy`` is the
-    gradient w.r.t. h (all channels, resolution per ``dy_mode``).  Returns (dx1, dx2, dgamma, dbeta); the
+    gradient w.r.t. h (all channels, resolution per ``dy_mode``); with ``drop_p`` > 0, h had been dropped out by
+    ``gn_apply(..., drop_seed, drop_p)`` and dy is masked the same way first.  Returns (dx1, dx2, dgamma, dbeta); the
     AdaGN gradients are written into ``dada`` (a view laid out like ``ada``).  ``add1``/``add2`` are further
     gradients reaching x, added into dx."""
     _dev(x1, x2, dy, coef, stat1, stat2, gamma, beta, add1, add2)
@@ -520,8 +522,8 @@ def gn_backward(x1: Tensor, dy: Tensor, coef: Tensor, stat1: Tensor, gamma: Tens
     code = _dtype_code(x1)
     nsg = gn_nsplit(H * W_)
     gsum = torch.empty((B, nsg, C, 2), dtype=torch.float32, device=x1.device)
-    check(lib.mad_gn_bwd_partial(_ptr(x1), C1, _ptr(x2), C2, _ptr(dy), dy_mode, _ptr(coef), int(act), code, _ptr(gsum),
-                                 B, H, W_, nsg, _stream()), "mad_gn_bwd_partial")
+    check(lib.mad_gn_bwd_partial(_ptr(x1), C1, _ptr(x2), C2, _ptr(dy), dy_mode, _ptr(coef), int(act), drop_seed, float(drop_p),
+                                 code, _ptr(gsum), B, H, W_, nsg, _stream()), "mad_gn_bwd_partial")
     bcoef = torch.empty((B, C, 4), dtype=torch.float32, device=x1.device)
     dgb = torch.empty((B, 2 * C), dtype=torch.float32, device=x1.device)
     ns1 = stat1.shape[1]
@@ -535,8 +537,8 @@ def gn_backward(x1: Tensor, dy: Tensor, coef: Tensor, stat1: Tensor, gamma: Tens
     if need_dx:
         dx1 = torch.empty_like(x1)
         dx2 = None if x2 is None else torch.empty_like(x2)
-        check(lib.mad_gn_bwd_apply(_ptr(x1), C1, _ptr(x2), C2, _ptr(dy), dy_mode, _ptr(coef), int(act), _ptr(bcoef),
-                                   _ptr(add1), add1_mode, _ptr(add2), add2_mode, _ptr(dx1), _ptr(dx2), code, B, H, W_,
+        check(lib.mad_gn_bwd_apply(_ptr(x1), C1, _ptr(x2), C2, _ptr(dy), dy_mode, _ptr(coef), int(act), drop_seed, float(drop_p),
+                                   _ptr(bcoef), _ptr(add1), add1_mode, _ptr(add2), add2_mode, _ptr(dx1), _ptr(dx2), code, B, H, W_,
                                    _stream()), "mad_gn_bwd_apply")
     return dx1, dx2, dg[:C], dg[C:]
 
@@ -584,12 +586,21 @@ def gn_coef(x1: Tensor, gamma: Tensor, beta: Tensor, groups: int, eps: float, x2
     return gn_finalize(gn_partial(x1, x2), H * W_, gamma, beta, groups, eps, ada=ada, ada_stride=ada_stride)
 
 
-def gn_apply(x1: Tensor, coef: Tensor, act: bool, x2: Optional[Tensor] = None, pool: bool = False) -> Tensor:
+def gn_apply(x1: Tensor, coef: Tensor, act: bool, x2: Optional[Tensor] = None, pool: bool = False,
+             drop_seed: int = 0, drop_p: float = 0.0) -> Tensor:
+    """y = act(x*a + d) (optionally 2x2-averaged); with ``drop_p`` > 0 the result is dropped out in the same pass
+    with the counter-based mask of ``drop_seed`` (training)."""
     _dev(x1, x2, coef)
     B, H, W_, C1 = x1.shape
     C2 = 0 if x2 is None else x2.shape[3]
     Ho, Wo = (H // 2, W_ // 2) if pool else (H, W_)
     y = torch.empty((B, Ho, Wo, C1 + C2), dtype=x1.dtype, device=x1.device)
+    if drop_p > 0.0:
+        if pool:
+            raise ValueError("gn_apply: dropout and pooling are not combined")
+        check(lib.mad_gn_apply_dropout(_ptr(x1), C1, _ptr(x2), C2, _ptr(coef), _ptr(y), _dtype_code(x1), B, H, W_, int(act),
+                                       drop_seed, float(drop_p), _stream()), "mad_gn_apply_dropout")
+        return y
     check(lib.mad_gn_apply(_ptr(x1), C1, _ptr(x2), C2, _ptr(coef), _ptr(y), _dtype_code(x1), B, H, W_, int(act),
                            int(pool), _stream()), "mad_gn_apply")
     return y

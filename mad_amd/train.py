@@ -167,11 +167,10 @@ class UNetTrainer:
         sv.h_part = self._part(sv.h, sv.h_part)
         sv.c1 = ops.gn_finalize(sv.h_part, hw_out, e["norm1.g"], e["norm1.b"], gn_groups(b.out_channels), GN_EPS,
                                 ada=ada_v, ada_stride=ada_total)
-        sv.h1 = ops.gn_apply(sv.h, sv.c1, act=True)
-        if self.dropout > 0.0:
+        if self.dropout > 0.0:                   # dropout fused into the apply pass; the backward rebuilds the mask
             self._drop_calls += 1
             sv.seed = (self.seed << 32) ^ (self.step_count << 12) ^ self._drop_calls
-            ops.dropout_(sv.h1, sv.seed, self.dropout)
+        sv.h1 = ops.gn_apply(sv.h, sv.c1, act=True, drop_seed=sv.seed or 0, drop_p=self.dropout if sv.seed is not None else 0.0)
         if b.skip_conv:
             res, mode = ops.conv2d(x, e["skip.w"], e["skip.b"], x2=skip), _lib.RES_SAME
         elif b.up:
@@ -278,11 +277,10 @@ class UNetTrainer:
         self._wgrad(f"{n}.conv1.weight", sv.h1, dy, 3)
         self._bgrad(f"{n}.conv1.bias", dy)
         dh1 = self._dgrad3(dy, _dgrad_weight(e, "conv1.w"))
-        if sv.seed is not None:
-            ops.dropout_(dh1, sv.seed, self.dropout)
         dh, _, dg, db = ops.gn_backward(sv.h, dh1, sv.c1, sv.h_part, e["norm1.g"], e["norm1.b"],
                                         gn_groups(b.out_channels), GN_EPS, act=True, ada=ada_v, ada_stride=ada_total,
-                                        dada=dada_v)
+                                        dada=dada_v, drop_seed=sv.seed or 0,
+                                        drop_p=self.dropout if sv.seed is not None else 0.0)
         self._set(f"{n}.norm1.weight", dg)
         self._set(f"{n}.norm1.bias", db)
         # conv0 (input possibly resampled after norm0 + SiLU)

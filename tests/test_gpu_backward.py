@@ -156,3 +156,37 @@ def test_attention_backward(dev, case):
     got = dqkv.float().cpu().reshape(B, L, heads, 3, 64)
     for i, name in enumerate("qkv"):
         assert rel_err(got[:, :, :, i], ref.grad[:, :, :, i]) < 1.5e-2, name
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_fused_dropout_forward_and_backward(dev, dt):
+    """gn_apply with dropout equals gn_apply followed by the stand-alone dropout kernel (same seed), about 10 %
+    of the elements are dropped, and gn_backward with the seed equals autograd through the masked activation."""
+    from mad_amd import ops
+    B, H, C, groups, seed, p = 2, 16, 64, 32, 0x1234567890, 0.1
+    q = (lambda t: t.to(dt).float()) if dt == torch.bfloat16 else (lambda t: t)
+    x = q(_rand((B, C, H, H), 1, 1.2))
+    gamma, beta = 1 + 0.2 * _rand((C,), 2), 0.2 * _rand((C,), 3)
+    dy = q(_rand((B, C, H, H), 4))
+    xn = _nhwc(x, dt, dev)
+    st = ops.gn_partial(xn)
+    coef = ops.gn_finalize(st, H * H, gamma.to(dev), beta.to(dev), groups, 1e-5)
+    plain = ops.gn_apply(xn, coef, act=True)
+    fused = ops.gn_apply(xn, coef, act=True, drop_seed=seed, drop_p=p)
+    two_pass = ops.dropout_(plain.clone(), seed, p)
+    assert torch.equal(fused == 0, two_pass == 0)                     # the same mask
+    if dt == torch.float32:
+        assert torch.equal(fused, two_pass)
+    else:                                                             # one rounding instead of two
+        assert rel_err(fused.float().cpu(), two_pass.float().cpu()) < 8e-3
+    mask = ops.dropout_(torch.ones_like(plain, dtype=torch.float32), seed, p)          # 0 or 1/(1-p), NHWC
+    frac = float((mask == 0).float().mean())
+    assert 0.08 < frac < 0.12 and abs(float(mask.max()) - 1 / (1 - p)) < 1e-6
+    xr = x.double().requires_grad_(True)
+    gr, br = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    hh = F.silu(F.group_norm(xr, groups, gr, br, eps=1e-5)) * mask.permute(0, 3, 1, 2).cpu().double()
+    (hh * dy.double()).sum().backward()
+    dx, _, dg, db = ops.gn_backward(xn, _nhwc(dy, dt, dev), coef, st, gamma.to(dev), beta.to(dev), groups, 1e-5, True,
+                                    drop_seed=seed, drop_p=p)
+    assert rel_err(dx.float().permute(0, 3, 1, 2).cpu(), xr.grad) < (2e-5 if dt == torch.float32 else 8e-3)
+    assert rel_err(dg.cpu(), gr.grad) < 1e-4 and rel_err(db.cpu(), br.grad) < 1e-4
