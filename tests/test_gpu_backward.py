@@ -41,6 +41,11 @@ WGRAD_CASES = [
     (2, 32, 32, 32, 32, 3, True),        # nearest x2 before the conv
     (1, 24, 48, 32, 40, 3, False),       # H multiple of 8 only, Cout multiple of 8 only
     (2, 12, 12, 24, 16, 3, False),       # generic kernel: shapes the MFMA form does not tile
+    (2, 16, 32, 128, 64, 3, False),      # large-tile form, 64 co x 128 ci slices
+    (2, 32, 32, 192, 192, 3, False),     # large-tile form, ragged in one dimension, several tiles per share
+    (3, 8, 8, 256, 128, 3, False),       # large-tile form on 8x8 images, odd batch
+    (2, 32, 32, 64, 128, 3, True),       # large-tile form with the nearest x2 in the loader
+    (5, 64, 64, 128, 128, 3, False),     # more tiles than shares: the double-buffered loop runs many rounds
 ]
 
 
