@@ -237,10 +237,11 @@ static int gn_apply_impl(const void* x1, int C1, const void* x2, int C2, const f
     MAD_REQUIRE(C1 > 0 && C1 % VEC == 0 && C2 >= 0 && C2 % VEC == 0 && (C2 == 0 || x2),
                 "mad_gn_apply: channels must be multiples of %d (C1=%d C2=%d)", VEC, C1, C2);
     MAD_REQUIRE(B > 0 && H > 0 && W > 0 && (!pool || (H % 2 == 0 && W % 2 == 0)), "mad_gn_apply: bad shape");
-    // pixel shares: about 2048 workgroups in all, at least 64 output pixels each
+    // pixel shares: about 2048 workgroups in all, at least one sweep of pixels each
     const int hwo = (pool ? H / 2 : H) * (pool ? W / 2 : W);
+    const int cpr = (C1 + C2) / VEC, rows = cpr >= 256 ? 1 : 256 / cpr;      // pixels a workgroup covers per sweep
     int shares = (2048 + B - 1) / B;
-    if (shares > (hwo + 63) / 64) shares = (hwo + 63) / 64;
+    if (shares > (hwo + rows - 1) / rows) shares = (hwo + rows - 1) / rows;
     if (shares < 1) shares = 1;
     dim3 grid(shares, B);
 #define LAUNCH(T, P)                                                                                              \

@@ -328,11 +328,11 @@ extern "C" int mad_gn_bwd_apply(const void* x1, int C1, const void* x2, int C2, 
     a.bcoef = bcoef; a.add1 = add1; a.add2 = add2; a.dx1 = dx1; a.dx2 = C2 ? dx2 : dx1;
     a.add1_mode = add1_mode; a.add2_mode = add2_mode;
     const int VEC = dtype == MAD_BF16 ? 8 : 4;
-    // pixel shares: about 2048 workgroups in all, at least 64 pixels each
+    // pixel shares: about 2048 workgroups in all, at least one sweep of pixels each
+    const int cpr = (C1 + C2) / VEC, rows = cpr >= 256 ? 1 : 256 / cpr;      // pixels a workgroup covers per sweep
     int shares = (2048 + B - 1) / B;
-    if (shares > (H * W + 63) / 64) shares = (H * W + 63) / 64;
+    if (shares > (H * W + rows - 1) / rows) shares = (H * W + rows - 1) / rows;
     if (shares < 1) shares = 1;
-    (void)VEC;
     const dim3 grid(shares, B);
     if (dtype == MAD_BF16) hipLaunchKernelGGL(gn_bwd_apply_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(gn_bwd_apply_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, a);
