@@ -17,7 +17,7 @@ buffers, so the data-parallel gradient sum is a handful of large RCCL all-reduce
 from __future__ import annotations
 
 import math
-from typing import Dict, List, Optional
+from typing import Dict, List, Optional, Tuple
 
 import torch
 from torch import Tensor
@@ -74,14 +74,14 @@ class UNetTrainer:
 
     def __init__(self, unet: DhariwalUNet, lr: float = 1e-4, betas=(0.95, 0.999), eps: float = 1e-7,
                  weight_decay: float = 1e-2, dropout: float = 0.10, ema: bool = True, ema_max_decay: float = 0.9999,
-                 ema_inv_gamma: float = 1.0, ema_power: float = 0.75, process_group=None, bucket_mb: int = 128,
+                 ema_inv_gamma: float = 1.0, ema_power: float = 0.75, process_group=None, bucket_mb: float = 128,
                  seed: int = 0):
         self.unet = unet
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
         self.dropout = float(dropout)
         self.ema_cfg = (ema_max_decay, ema_inv_gamma, ema_power)
         self.group = process_group
-        self.bucket_elems = bucket_mb * (1 << 20) // 4
+        self.bucket_elems = max(1, int(bucket_mb * (1 << 20)) // 4)
         self.step_count = 0
         self.seed = seed
         self._drop_calls = 0
@@ -107,6 +107,27 @@ class UNetTrainer:
             off += n
         self.ema = self.flat.clone() if ema else None
         unet.invalidate()
+        # Buckets for the data-parallel sum: runs of consecutive parameters of at least `bucket_mb`.  The backward
+        # writes gradients roughly from the last parameter to the first, so a bucket is complete -- and its
+        # all-reduce can start, overlapping the rest of the backward -- when all of its parameters are written.
+        self.buckets: List[Tuple[int, int]] = []          # [lo, hi) ranges of the flat buffer
+        self._bucket_of: Dict[str, int] = {}
+        self._bucket_size: List[int] = []
+        lo = off = cnt = 0
+        for name, p in params:
+            self._bucket_of[name] = len(self.buckets)
+            off += p.numel()
+            cnt += 1
+            if off - lo >= self.bucket_elems:
+                self.buckets.append((lo, off)); self._bucket_size.append(cnt)
+                lo, cnt = off, 0
+        if off > lo:
+            self.buckets.append((lo, off)); self._bucket_size.append(cnt)
+        self._pending: List[int] = []
+        self._works: list = []
+        self._launched: List[int] = []                     # bucket indices in launch order (last backward)
+        self._overlap = False
+        self._reduce_fn = None                             # test hook: called instead of dist.all_reduce
 
     # ------------------------------------------------------------------ helpers
     def _set(self, name: str, g: Tensor) -> None:
@@ -116,13 +137,36 @@ class UNetTrainer:
             dst.add_(g.reshape(dst.shape))
         else:
             dst.copy_(g.reshape(dst.shape))
+        self._mark(name)
+
+    def _mark(self, name: str) -> None:
+        """Parameter ``name``'s gradient is final for this backward: start its bucket's all-reduce when the bucket is whole."""
+        if not self._overlap:
+            return
+        b = self._bucket_of[name]
+        self._pending[b] -= 1
+        if self._pending[b] == 0:
+            self._launch(b)
+
+    def _launch(self, b: int) -> None:
+        lo, hi = self.buckets[b]
+        self._launched.append(b)
+        if self._reduce_fn is not None:
+            self._reduce_fn(lo, hi)
+            return
+        import torch.distributed as dist
+        # the collective is ordered after the kernels already queued on the current stream and runs on the
+        # process group's own stream, beside the rest of the backward
+        self._works.append(dist.all_reduce(self.gflat[lo:hi], group=self.group, async_op=True))
 
     def _wgrad(self, name: str, x: Tensor, dy: Tensor, ksize: int, upsample: bool = False) -> None:
         """Conv weight gradient written (or, when accumulating micro-batches, added) straight into the flat buffer."""
         ops.conv_wgrad(x, dy, ksize, upsample=upsample, out=self.grads[name], accumulate=self._accumulating)
+        self._mark(name)
 
     def _bgrad(self, name: str, dy: Tensor) -> None:
         ops.bias_grad(dy, out=self.grads[name], accumulate=self._accumulating)
+        self._mark(name)
 
     @staticmethod
     def _conv3(x: Tensor, w: Tensor, b: Optional[Tensor], upsample: bool = False, residual: Optional[Tensor] = None,
@@ -268,6 +312,8 @@ class UNetTrainer:
             else:
                 self.grads[f"{n}.qkv.weight"].index_copy_(0, idx, gw)
                 self.grads[f"{n}.qkv.bias"].index_copy_(0, idx, gb)
+            self._mark(f"{n}.qkv.weight")
+            self._mark(f"{n}.qkv.bias")
             dhn = ops.conv2d(dqkv, _dgrad_weight(e, "qkv.w"), None)
             dy, _, dg, db = ops.gn_backward(sv.y, dhn, sv.c2, sv.y_part, e["norm2.g"], e["norm2.b"],
                                             gn_groups(b.out_channels), GN_EPS, act=False, add1=dout)
@@ -300,6 +346,7 @@ class UNetTrainer:
                         gsk[:, sl].add_(g)
                     else:
                         gsk[:, sl].copy_(g)
+                self._mark(f"{n}.skip.weight")
             self._bgrad(f"{n}.skip.bias", dy)
             dres, res_mode = ops.conv2d(dy, _dgrad_weight(e, "skip.w"), None), ops.GRAD_SAME
         else:
@@ -401,11 +448,17 @@ class UNetTrainer:
 
     # ------------------------------------------------------------------ step
     def forward_backward(self, x_t: Tensor, t: Tensor, class_labels: Optional[Tensor], target: Tensor,
-                         accumulate: bool = False) -> Tensor:
+                         accumulate: bool = False, last: bool = True) -> Tensor:
         """Loss of one micro-batch and its gradients; ``accumulate`` adds to the gradients already held
-        (``accelerator.accumulate``, main.py:239)."""
+        (``accelerator.accumulate``, main.py:239).  On the ``last`` micro-batch of an optimizer step each bucket's
+        all-reduce is started as soon as the backward has written the bucket (data-parallel runs only)."""
+        import torch.distributed as dist
         self._drop_calls = 0
         self._accumulating = bool(accumulate) and self.micro_batches > 0
+        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
+        self._overlap = bool(last) and (multi or self._reduce_fn is not None)
+        self._pending = list(self._bucket_size)
+        self._launched, self._works = [], []
         pred, tape = self.forward(x_t, t, class_labels)
         loss, dpred = ops.mse_loss_grad(pred, target.to(torch.float32))
         self.backward(tape, dpred)
@@ -414,8 +467,15 @@ class UNetTrainer:
         return loss
 
     def sync_grads(self) -> None:
-        """Sum the gradients over the data-parallel ranks; the division by the world size (and by the number
-        of accumulated micro-batches) is folded into the update."""
+        """Finish the data-parallel sum of the gradients: buckets the backward did not start (no overlap requested)
+        are reduced now, then every collective is awaited.  The division by the world size (and by the number of
+        accumulated micro-batches) is folded into the update."""
+        if self._overlap:
+            assert all(p == 0 for p in self._pending), "a parameter's gradient was never written"
+            for w in self._works:
+                w.wait()
+            self._works, self._overlap = [], False
+            return
         allreduce_flat(self.gflat, self.bucket_elems, self.group)
 
     def ema_decay(self) -> float:
@@ -444,14 +504,15 @@ class UNetTrainer:
         import torch.distributed as dist
         alphas = alphas_cumprod.to(x0.device)
         total = None
-        for xs, ls in zip(x0.chunk(accumulation), (class_labels.chunk(accumulation) if class_labels is not None
-                                                   else [None] * accumulation)):
+        chunks = list(zip(x0.chunk(accumulation), (class_labels.chunk(accumulation) if class_labels is not None
+                                                    else [None] * accumulation)))
+        for i, (xs, ls) in enumerate(chunks):
             B = xs.shape[0]
             t = torch.randint(0, num_timesteps, (B,), device=x0.device, generator=generator)
             noise = torch.randn(xs.shape, device=x0.device, dtype=torch.float32, generator=generator)
             a = alphas[t].to(torch.float32)
             x_t = a.sqrt().view(B, 1, 1, 1) * xs + (1.0 - a).sqrt().view(B, 1, 1, 1) * noise     # add_noise, main.py:237
-            loss = self.forward_backward(x_t, t.to(torch.float32), ls, noise, accumulate=True)
+            loss = self.forward_backward(x_t, t.to(torch.float32), ls, noise, accumulate=True, last=i == len(chunks) - 1)
             total = loss if total is None else total + loss
         self.sync_grads()
         ws = dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1

@@ -173,3 +173,26 @@ def test_data_parallel_and_accumulated_steps_equal_the_big_batch(dev):
     acc.step()
     assert rel_err(acc.flat.cpu(), whole.flat.cpu()) < 1e-5
     assert rel_err(acc.ema.cpu(), whole.ema.cpu()) < 1e-5
+
+
+def test_buckets_are_reduced_once_and_only_when_complete(dev):
+    """The overlap bookkeeping, with the collective replaced by a recorder: every bucket of the flat gradient is
+    handed over exactly once, in roughly reverse parameter order, and nothing writes into it afterwards."""
+    from mad_amd.train import UNetTrainer
+    cfg, m, sd, x, t, lab, target = _setup("model_tiny.yaml", "bf16", dev, B=2)
+    tr = UNetTrainer(m.unet, dropout=0.1, bucket_mb=0.5)
+    assert len(tr.buckets) > 4 and tr.buckets[0][0] == 0 and tr.buckets[-1][1] == tr.gflat.numel()
+    assert all(a[1] == b[0] for a, b in zip(tr.buckets, tr.buckets[1:]))
+    seen = []
+    tr._reduce_fn = lambda lo, hi: seen.append((lo, hi, tr.gflat[lo:hi].clone()))
+    x, t, lab, target = (v.to(dev) for v in (x, t, lab, target))
+    tr.forward_backward(x, t, lab, target, accumulate=True, last=False)        # first micro-batch: nothing handed over
+    assert not seen
+    tr.forward_backward(x, t, lab, target, accumulate=True, last=True)
+    tr.sync_grads()
+    assert sorted((lo, hi) for lo, hi, _ in seen) == tr.buckets
+    for lo, hi, snap in seen:
+        assert torch.equal(snap, tr.gflat[lo:hi])
+    order = tr._launched
+    assert order[0] > order[-1]                         # the tail of the parameter list completes first
+    assert seen[0][2].abs().max() > 0
