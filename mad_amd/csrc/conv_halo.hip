@@ -30,6 +30,7 @@ struct HaloArgs {
     const void* residual; void* y; float* stats;
     int C1, C2, B, H, W, Cout, upsample, res_mode, act;
     int Hs, Ws, tiles_x, tiles_y, ntiles_n;
+    int n_off;                 // first output channel of this launch (a layer may be split over two launches)
     // optional 1x1 projection of a second input added to the result (extra K-tiles, centre tap only)
     const void* sx1; const void* sx2; const void* sw;
     int SC1, SC2;
@@ -107,7 +108,7 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / 2) void conv3x3_halo_kernel
     const int tile = logical % tiles_img;
     const int b = logical / tiles_img;
     const int ty0 = (tile / a.tiles_x) * HT, tx0 = (tile % a.tiles_x) * HT;
-    const int n0 = nt * BN;
+    const int n0 = a.n_off + nt * BN;
 
     const int Ctot = a.C1 + a.C2;
     const int nchunks = Ctot / CK;
@@ -581,12 +582,21 @@ static int conv3x3_fused_impl(const void* x1, int C1, const void* x2, int C2, co
     a.stream_out = (size_t)B * H * W * Cout * (dtype == MAD_BF16 ? 2 : 4) > ((size_t)256 << 20);
     hipStream_t s = (hipStream_t)stream;
     const char* what = "mad_conv3x3_fused";
-    // 128 output channels per workgroup unless that leaves the chip (256 CUs, two workgroups each)
-    // under-filled or Cout is an odd multiple of 64: then 64 per workgroup.
+    // 128 output channels per workgroup unless that leaves the chip (256 CUs, two workgroups each) under-filled:
+    // then 64 per workgroup.  An odd multiple of 64 is split over two launches: the wide form for the first
+    // Cout - 64 channels and the narrow form for the last 64 (each reads the whole input).
     const int wg128 = B * a.tiles_x * a.tiles_y * (Cout / 128);
-    bool narrow = Cout % 128 != 0 || wg128 < 256;
-    if (const char* f = getenv("MAD_HALO_BN")) narrow = Cout % 128 != 0 || atoi(f) == 64;   // tuning aid
-    a.ntiles_n = Cout / (narrow ? 64 : 128);
+    // (the narrow tail launch has one workgroup per pixel tile: it must fill the chip on its own)
+    const int wgtail = B * a.tiles_x * a.tiles_y;
+    int mode = Cout % 128 == 0 ? (wg128 < 256 ? 64 : 128) : (Cout > 64 && wgtail >= 512 ? 192 : 64);
+    if (const char* f = getenv("MAD_HALO_BN")) {                                  // tuning aid
+        const int v = atoi(f);
+        if (v == 64) mode = 64;
+        else if (v == 128 && Cout % 128 == 0) mode = 128;
+        else if (v == 192 && Cout % 128 == 64 && Cout > 64) mode = 192;
+        else if (v == 0 && mode == 192) mode = 64;                                 // no split
+    }
+    auto run = [&](bool narrow) -> int {
 #define MAD_HALO_DISPATCH(T_, TN_)                                                                    \
     do {                                                                                              \
         if (SC1 > 0)                                                                                  \
@@ -595,13 +605,23 @@ static int conv3x3_fused_impl(const void* x1, int C1, const void* x2, int C2, co
         return coef ? launch_halo<T_, true, 2, 2, TN_, false>(a, s, what)                             \
                     : launch_halo<T_, false, 2, 2, TN_, false>(a, s, what);                           \
     } while (0)
-    if (dtype == MAD_BF16) {
-        if (narrow) MAD_HALO_DISPATCH(bf16_t, 1);
-        MAD_HALO_DISPATCH(bf16_t, 2);
-    }
-    if (narrow) MAD_HALO_DISPATCH(float, 1);
-    MAD_HALO_DISPATCH(float, 2);
+        if (dtype == MAD_BF16) {
+            if (narrow) MAD_HALO_DISPATCH(bf16_t, 1);
+            MAD_HALO_DISPATCH(bf16_t, 2);
+        }
+        if (narrow) MAD_HALO_DISPATCH(float, 1);
+        MAD_HALO_DISPATCH(float, 2);
 #undef MAD_HALO_DISPATCH
+    };
+    a.n_off = 0;
+    if (mode == 192) {
+        a.ntiles_n = Cout / 128;
+        if (int rc = run(false)) return rc;
+        a.n_off = Cout - 64; a.ntiles_n = 1;
+        return run(true);
+    }
+    a.ntiles_n = Cout / mode;
+    return run(mode == 64);
 }
 
 extern "C" int mad_conv3x3_fused(const void* x1, int C1, const void* x2, int C2, const float* coef, int act,
@@ -641,7 +661,7 @@ extern "C" int mad_conv_out_fused(const void* x, int Cin, const float* coef, int
     a.C1 = Cin; a.C2 = 0; a.B = B; a.H = H; a.W = W; a.Cout = Cout; a.upsample = 0; a.res_mode = MAD_RES_NONE;
     a.act = act; a.Hs = H; a.Ws = W;
     a.sx1 = a.sx2 = a.sw = nullptr; a.SC1 = a.SC2 = 0; a.stream_out = 0;
-    a.tiles_x = W / HT; a.tiles_y = H / HT; a.ntiles_n = 1;
+    a.tiles_x = W / HT; a.tiles_y = H / HT; a.ntiles_n = 1; a.n_off = 0;
     hipStream_t s = (hipStream_t)stream;
     const char* what = "mad_conv_out_fused";
     if (dtype == MAD_BF16)

@@ -312,17 +312,21 @@ FUSED_CASES = [
     (1, 32, 64, 0, 128, False, False, "down", False),     # plain input, 2x2-mean residual
     (1, 64, 160, 0, 128, True, False, "same", True),      # 5 bf16 chunks / 10 fp32 chunks
     (1, 32, 96, 0, 192, True, False, "same", True),       # Cout an odd multiple of 64
+    (2, 32, 64, 32, 320, True, False, "same", True),      # 2 x 128 + 64 output channels, two sources
 ]
 
 
 @pytest.mark.parametrize("case", FUSED_CASES)
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("bn", ["128", "64"])
+@pytest.mark.parametrize("bn", ["128", "64", "192"])
 def test_conv3x3_fused(dev, case, dt, bn, monkeypatch):
-    """Both workgroup widths (128 and 64 output channels) of the halo-tile kernel."""
+    """Both workgroup widths (128 and 64 output channels) of the halo-tile kernel, and ("192") the split of an
+    odd multiple of 64 channels over a wide and a narrow launch."""
     from mad_amd import _lib, ops
     monkeypatch.setenv("MAD_HALO_BN", bn)
     B, H, C1, C2, Cout, fuse, up, res, want_stats = case
+    if bn == "192" and Cout % 128 != 64:
+        pytest.skip("the split applies to odd multiples of 64 channels")
     C = C1 + C2
     Hs = H // 2 if up else H
     x1 = _rand((B, C1, Hs, Hs), 1, 1.3) + 0.2
