@@ -67,6 +67,52 @@ def cpu_baseline(spec, B):
             "sample": f"one micro-batch of 1 image: forward + autograd backward + AdamW in {dt:.1f} s (fp32, no dropout)"}
 
 
+def hbm_kernels(dev, B, R, C, nparams, iters=10):
+    """Achieved GB/s of the bandwidth-bound training kernels on the workload's largest activation shape
+    (outside the timed region): GroupNorm backward partial sums (4 B/element: x, dy) and apply (6 B/element:
+    x, dy in, dx out), forward apply with dropout (4 B/element), the fused AdamW+EMA update (36 B/parameter)."""
+    from mad_amd import ops
+    from mad_amd.unet_spec import gn_groups
+
+    def timed(fn):
+        for _ in range(2):
+            fn()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        a.record()
+        for _ in range(iters):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) / iters * 1e-3
+
+    out = {}
+    x = torch.randn(B, R, R, C, device=dev).to(torch.bfloat16)
+    dy = torch.randn(B, R, R, C, device=dev).to(torch.bfloat16)
+    gamma, beta = torch.ones(C, device=dev), torch.zeros(C, device=dev)
+    st = ops.gn_partial(x)
+    coef = ops.gn_finalize(st, R * R, gamma, beta, gn_groups(C), 1e-5)
+    nsg = ops.gn_nsplit(R * R)
+    gsum = torch.empty((B, nsg, C, 2), dtype=torch.float32, device=dev)
+    bcoef = torch.rand((B, C, 4), device=dev) * 0.1
+    dx = torch.empty_like(x)
+    code = ops._dtype_code(x)
+    t = timed(lambda: ops.check(ops.lib.mad_gn_bwd_partial(x.data_ptr(), C, None, 0, dy.data_ptr(), 0, coef.data_ptr(), 1, 0, 0.0,
+                                                           code, gsum.data_ptr(), B, R, R, nsg, ops._stream()), "mad_gn_bwd_partial"))
+    out["gn_bwd_partial"] = {"GB/s": 4.0 * x.numel() / t / 1e9, "bytes_per_element": 4, "us": t * 1e6}
+    t = timed(lambda: ops.check(ops.lib.mad_gn_bwd_apply(x.data_ptr(), C, None, 0, dy.data_ptr(), 0, coef.data_ptr(), 1, 0, 0.0,
+                                                         bcoef.data_ptr(), None, 0, None, 0, dx.data_ptr(), None, code, B, R, R,
+                                                         ops._stream()), "mad_gn_bwd_apply"))
+    out["gn_bwd_apply"] = {"GB/s": 6.0 * x.numel() / t / 1e9, "bytes_per_element": 6, "us": t * 1e6}
+    t = timed(lambda: ops.gn_apply(x, coef, act=True, drop_seed=7, drop_p=0.1))
+    out["gn_apply_dropout"] = {"GB/s": 4.0 * x.numel() / t / 1e9, "bytes_per_element": 4, "us": t * 1e6}
+    del x, dy, dx
+    p, g, m, v, e = (torch.rand(nparams, device=dev) for _ in range(5))
+    t = timed(lambda: ops.adamw_step_(p, g, m, v, e, 1e-4, 0.95, 0.999, 1e-7, 1e-2, 3, ema_decay=0.9))
+    out["adamw_ema"] = {"GB/s": 36.0 * nparams / t / 1e9, "bytes_per_parameter": 36, "us": t * 1e6}
+    return out
+
+
 def main():
     args = parse_args()
     rank = int(os.environ.get("RANK", "0"))
@@ -164,6 +210,7 @@ def main():
                          "mfma_kernels": {k: {"tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12, "ms_per_pass": v["ms"],
                                               "launches": v["launches"]} for k, v in mfma.items()}},
         }
+        line["hbm_kernels"] = hbm_kernels(dev, B * accum // passes, R, spec.model_channels, int(tr.flat.numel()))
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(spec, B)
         print(json.dumps(line), flush=True)
