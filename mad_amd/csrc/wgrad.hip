@@ -9,7 +9,7 @@
 // operand; A (dY) and B (X) use the same pixel order inside a 16-pixel step.
 //
 // One workgroup owns a (128 output channels) x (32 input channels) x (all taps) slice of dW and walks a
-// strided share of the pixel tiles (8 rows x 16 columns of one image, or two 8x8 images); wave w keeps
+// strided share of the pixel tiles (4 rows x 16 columns of one image, or one 8x8 image); wave w keeps
 // the 32 output channels 32w.. of every tap in registers (9 accumulators).  The input halo of a tile is
 // staged once and the taps read it at shifted pixel offsets.  Workgroups that share a slice write their
 // sums to separate partial buffers, which a second kernel adds in a fixed order (deterministic).
@@ -23,12 +23,13 @@ struct WgradArgs {
 };
 
 namespace wg {
-constexpr int TPIX = 128;                  // pixels per tile
+constexpr int TPIX = 64;                   // pixels per tile
 constexpr int YROW = 256;                  // bytes of dY per pixel in LDS: 128 bf16 output channels
 constexpr int XROW = 64;                   // bytes of X per halo pixel in LDS: 32 bf16 input channels
-constexpr int OFF_X = TPIX * YROW;         // 32 KiB
-constexpr int X_BYTES = 13 * 1024;         // up to 208 halo pixels
-constexpr int LDS_BYTES = OFF_X + X_BYTES;
+constexpr int OFF_X = TPIX * YROW;         // 16 KiB
+constexpr int X_BYTES = 7 * 1024;          // up to 112 halo pixels
+constexpr int STAGE = OFF_X + X_BYTES;
+constexpr int LDS_BYTES = 2 * STAGE;       // the tile being multiplied and the tile being copied
 }  // namespace wg
 
 typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
@@ -40,14 +41,23 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* lo, const unsigne
     return bf16x8{l[0], l[1], l[2], l[3], h[0], h[1], h[2], h[3]};
 }
 
-// KS: 1 or 3.  SW: 16 = a tile is 8 rows x 16 columns of one image (H % 8 == 0, W % 16 == 0);
-//              8 = a tile is two whole 8x8 images.
+// pointer select by masking: the compiler cannot turn it back into a branch around the address arithmetic
+__device__ __forceinline__ const void* pick_ptr(bool ok, const void* p, const void* other) {
+    const uintptr_t m = (uintptr_t)0 - (uintptr_t)ok;
+    return (const void*)(((uintptr_t)p & m) | ((uintptr_t)other & ~m));
+}
+
+// KS: 1 or 3.  SW: 16 = a tile is 4 rows x 16 columns of one image (H % 4 == 0, W % 16 == 0);
+//              8 = a tile is one whole 8x8 image.
+// Two tiles are resident: the copies of the next tile are issued right after the barrier that hands over the
+// current one and land while it is multiplied.  A dY piece's pixel is (compile-time piece row) + (per-lane
+// pixel), so its address is a per-lane offset plus scalars.
 template <int KS, int SW>
 __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs a) {
     using namespace wg;
     constexpr int PAD = KS / 2, NT = KS * KS;
-    constexpr int NIMG = 16 / SW, SH = 8;
-    constexpr int HPW = SW + 2 * PAD, HPH = SH + 2 * PAD, HPIX = NIMG * HPH * HPW;
+    constexpr int SH = SW == 16 ? 4 : 8;
+    constexpr int HPW = SW + 2 * PAD, HPH = SH + 2 * PAD, HPIX = HPH * HPW;
     constexpr int XPIECES = (HPIX + 15) / 16;
     static_assert(XPIECES * 1024 <= X_BYTES, "halo region");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -74,58 +84,77 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs a) {
     const int a_lchunk = 4 * wave + (g & 1) * 2 + (pp >> 1);            // 16-byte chunk of this wave's 32 channels
     const int a_off = ((a_lchunk ^ (q << 2)) << 4) + (pp & 1) * 8;      // chunk index XOR (pixel & 3) << 2
     const int b_off = (g & 1) * 32 + pp * 8;
-    const int tpi = SW == 16 ? (a.H >> 3) * (a.W >> 4) : 1;             // tiles per image
+    const int tpi = SW == 16 ? (a.H >> 2) * (a.W >> 4) : 1;             // tiles per image
     const int tpr = SW == 16 ? (a.W >> 4) : 1;
 
-    for (int tile = ks; tile < a.ntiles; tile += a.ksplit) {
+    // dY copies: piece j*4+wave holds pixels 16j + pl, pl = 4*wave + lane/16; chunk c of pixel p holds logical
+    // chunk c ^ ((p&3)<<2)
+    const int pl = 4 * wave + (lane >> 4);
+    const int y_px = SW == 16 ? pl : (pl & 7), y_py = SW == 16 ? 0 : (pl >> 3);
+    const int y_co = co0 + (((lane & 15) ^ ((pl & 3) << 2)) << 3);
+    const bool y_ok = y_co < a.Cout;                                      // Cout is a multiple of 8
+    const int y_lane_off = (y_py * a.W + y_px) * a.Cout + y_co;
+    const int y_piece_stride = (SW == 16 ? 1 : 2) * a.W * a.Cout;         // rows 16 (or 8+8) pixels apart
+
+    auto stage = [&](int tile, int buf) {
         int b0, y0, x0;
-        if (SW == 16) { b0 = tile / tpi; const int r = tile - b0 * tpi; y0 = (r / tpr) * 8; x0 = (r % tpr) * 16; }
-        else { b0 = tile * 2; y0 = 0; x0 = 0; }
-        __syncthreads();                                 // the previous tile is consumed
-        // ---- dY: 32 pieces of 4 pixels x 256 bytes, chunk c of pixel p holds logical chunk c ^ ((p&3)<<2)
+        if (SW == 16) { b0 = tile / tpi; const int r = tile - b0 * tpi; y0 = (r / tpr) * 4; x0 = (r % tpr) * 16; }
+        else { b0 = tile; y0 = 0; x0 = 0; }
+        const unsigned base = lds0 + buf * STAGE;
+        const bf16_t* ytile = DY + ((size_t)(b0 * a.H + y0) * a.W + x0) * a.Cout + y_lane_off;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < 4; ++j)
+            glds16(pick_ptr(y_ok, ytile + (size_t)j * y_piece_stride, g_zero_page),
+                   __builtin_amdgcn_readfirstlane(base + (j * 4 + wave) * 1024));
+        // X halo: pieces of 16 halo pixels x 64 bytes
+        const bf16_t* ximg = X + (size_t)b0 * Hs * Ws * a.Cin + ci0 + (lane & 3) * 8;
+#pragma unroll
+        for (int j = 0; j < (XPIECES + 3) / 4; ++j) {
             const int piece = j * 4 + wave;
-            const int p = piece * 4 + (lane >> 4);
-            const int img = SW == 16 ? 0 : p >> 6;
-            const int py = SW == 16 ? p >> 4 : (p >> 3) & 7, px = SW == 16 ? p & 15 : p & 7;
-            const int lc = (lane & 15) ^ ((p & 3) << 2);
-            const int co = co0 + lc * 8;
-            const bool ok = (b0 + img) < a.B && co < a.Cout;            // Cout is a multiple of 8
-            const bf16_t* src = DY + ((size_t)((b0 + img) * a.H + y0 + py) * a.W + x0 + px) * a.Cout + co;
-            glds16(ok ? (const void*)src : (const void*)g_zero_page,
-                   __builtin_amdgcn_readfirstlane(lds0 + piece * 1024));
-        }
-        // ---- X halo: pieces of 16 halo pixels x 64 bytes
-        for (int piece = wave; piece < XPIECES; piece += 4) {
-            const int hp = piece * 16 + (lane >> 2);
-            const int img = hp / (HPH * HPW), r = hp - img * (HPH * HPW);
-            const int hy = r / HPW, hx = r - hy * HPW;
-            const int yy = y0 + hy - PAD, xx = x0 + hx - PAD;
-            const bool ok = hp < HPIX && (b0 + img) < a.B && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
+            const unsigned hp = piece * 16 + (lane >> 2);
+            const unsigned hy = hp / HPW, hx = hp - hy * HPW;
+            const int yy = y0 + (int)hy - PAD, xx = x0 + (int)hx - PAD;
+            const bool ok = (hp < (unsigned)HPIX) & ((unsigned)yy < (unsigned)a.H) & ((unsigned)xx < (unsigned)a.W);
             const int sy = a.upsample ? yy >> 1 : yy, sx = a.upsample ? xx >> 1 : xx;
-            const bf16_t* src = X + ((size_t)((b0 + img) * Hs + sy) * Ws + sx) * a.Cin + ci0 + (lane & 3) * 8;
-            glds16(ok ? (const void*)src : (const void*)g_zero_page,
-                   __builtin_amdgcn_readfirstlane(lds0 + OFF_X + piece * 1024));
+            if (XPIECES % 4 == 0 || piece < XPIECES)                      // wave-uniform
+                glds16(pick_ptr(ok, ximg + (sy * Ws + sx) * a.Cin, g_zero_page),
+                       __builtin_amdgcn_readfirstlane(base + OFF_X + piece * 1024));
         }
+    };
+
+    int buf = 0;
+    if (ks < a.ntiles) stage(ks, 0);
+    for (int tile = ks; tile < a.ntiles; tile += a.ksplit) {
         dma_wait_all();
-        __syncthreads();
-#pragma unroll 2
-        for (int s = 0; s < 8; ++s) {
-            const int pa = 16 * s + 4 * h + q;                           // tile pixel of the low half
-            const bf16x8 af = tr_frag(smem + pa * YROW + a_off, smem + (pa + 8) * YROW + a_off);
-            // halo pixel of (row, x) of this step at tap (0,0)
-            int hp_lo, hp_hi;
-            if (SW == 16) { hp_lo = s * HPW + 4 * h + q; hp_hi = hp_lo + 8; }
-            else { hp_lo = (s >> 2) * (HPH * HPW) + 2 * (s & 3) * HPW + 4 * h + q; hp_hi = hp_lo + HPW; }
+        __syncthreads();                     // this tile has landed and the other stage has been consumed
+        if (tile + a.ksplit < a.ntiles) stage(tile + a.ksplit, buf ^ 1);
+        const unsigned char* ys = smem + buf * STAGE;
+        const unsigned char* xs = ys + OFF_X;
+        // The shifted-X operand of tap row ky at step s covers halo rows RS*s + ky (and the next one when a step
+        // is two image rows): the operand of (s, ky) is the operand of (s + 1, ky - RS), so it is read from LDS
+        // once and kept in registers until its last use.
+        constexpr int RS = SW == 16 ? 1 : 2;
+        bf16x8 xf[3 * RS + KS][KS];
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const int sh = (t / KS) * HPW + (t % KS);
-                const bf16x8 bf = tr_frag(smem + OFF_X + (hp_lo + sh) * XROW + b_off,
-                                          smem + OFF_X + (hp_hi + sh) * XROW + b_off);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[t], 0, 0, 0);
+        for (int s = 0; s < 4; ++s) {
+            const int pa = 16 * s + 4 * h + q;                           // tile pixel of the low half
+            const bf16x8 af = tr_frag(ys + pa * YROW + a_off, ys + (pa + 8) * YROW + a_off);
+#pragma unroll
+            for (int ky = 0; ky < KS; ++ky) {
+                const int R = RS * s + ky;
+                if (s == 0 || R > RS * (s - 1) + KS - 1) {               // first use of halo row R
+#pragma unroll
+                    for (int kx = 0; kx < KS; ++kx) {
+                        const int hp_lo = R * HPW + kx + 4 * h + q, hp_hi = hp_lo + (SW == 16 ? 8 : HPW);
+                        xf[R][kx] = tr_frag(xs + hp_lo * XROW + b_off, xs + hp_hi * XROW + b_off);
+                    }
+                }
+#pragma unroll
+                for (int kx = 0; kx < KS; ++kx)
+                    acc[ky * KS + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, xf[R][kx], acc[ky * KS + kx], 0, 0, 0);
             }
         }
+        buf ^= 1;
     }
     // ---- partial[ks][co][tap][ci]
     float* out = a.partial + (size_t)ks * a.Cout * NT * a.Cin;
@@ -291,10 +320,14 @@ __global__ void wgrad_edge_reduce_kernel(const float* partial, float* dw, int ns
     dw[o] = accumulate ? dw[o] + s : s;
 }
 
+// Two workgroups are resident per CU (256 CUs): one full round of the chip, since a second, partly filled
+// round would idle CUs and every extra split adds a partial buffer to write and reduce.
 static int pick_ksplit(int slices, int ntiles) {
-    int k = (3 * 256 + slices - 1) / slices;             // about three workgroups per CU in total
+    const char* e = getenv("MAD_WGRAD_SLOTS");
+    const int slots = e ? atoi(e) : 512;
+    int k = slots / slices;
     if (k > ntiles) k = ntiles;
-    if (k > 64) k = 64;
+    if (k > 256) k = 256;
     return k < 1 ? 1 : k;
 }
 
@@ -310,7 +343,7 @@ static bool wgrad_mfma_ok(int dtype, int H, int W, int Cin, int Cout, int ksize)
 
 static int wgrad_ksplit(int dtype, int B, int H, int W, int Cin, int Cout, int ksize, int* ntiles_out) {
     if (wgrad_mfma_ok(dtype, H, W, Cin, Cout, ksize)) {
-        const int ntiles = (H == 8 && W == 8) ? (B + 1) / 2 : B * (H / 8) * (W / 16);
+        const int ntiles = (H == 8 && W == 8) ? B : B * (H / 4) * (W / 16);
         if (ntiles_out) *ntiles_out = ntiles;
         return pick_ksplit(((Cout + 127) / 128) * (Cin / 32), ntiles);
     }
