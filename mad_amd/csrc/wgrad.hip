@@ -19,7 +19,7 @@ namespace mad {
 
 struct WgradArgs {
     const void* x; const void* dy; float* partial;
-    int B, H, W, Cin, Cout, ksplit, ntiles, upsample;
+    int B, H, W, Cin, Cout, ksplit, ntiles, upsample, dbg;
 };
 
 namespace wg {
@@ -28,8 +28,8 @@ constexpr int YROW = 256;                  // bytes of dY per pixel in LDS: 128 
 constexpr int XROW = 64;                   // bytes of X per halo pixel in LDS: 32 bf16 input channels
 constexpr int OFF_X = TPIX * YROW;         // 16 KiB
 constexpr int X_BYTES = 7 * 1024;          // up to 112 halo pixels
-constexpr int STAGE = OFF_X + X_BYTES;
-constexpr int LDS_BYTES = 2 * STAGE;       // the tile being multiplied and the tile being copied
+// the X region of a workgroup with WCI groups of input channels is WCI * X_BYTES; two stages are resident:
+// the tile being multiplied and the tile being copied
 }  // namespace wg
 
 typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
@@ -52,22 +52,26 @@ __device__ __forceinline__ const void* pick_ptr(bool ok, const void* p, const vo
 // Two tiles are resident: the copies of the next tile are issued right after the barrier that hands over the
 // current one and land while it is multiplied.  A dY piece's pixel is (compile-time piece row) + (per-lane
 // pixel), so its address is a per-lane offset plus scalars.
-template <int KS, int SW>
-__global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs a) {
+// WCI: 1 = four waves, a 128 x 32 slice, two workgroups per CU; 2 = eight waves (wave = (ci group, co group)),
+// a 128 x 64 slice, one workgroup per CU: the dY tile is copied once for both ci groups and half as many
+// partial sums are written.
+template <int KS, int SW, int WCI>
+__global__ __launch_bounds__(256 * WCI, 2 / WCI) void wgrad_mfma_kernel(WgradArgs a) {
     using namespace wg;
     constexpr int PAD = KS / 2, NT = KS * KS;
     constexpr int SH = SW == 16 ? 4 : 8;
     constexpr int HPW = SW + 2 * PAD, HPH = SH + 2 * PAD, HPIX = HPH * HPW;
     constexpr int XPIECES = (HPIX + 15) / 16;
     static_assert(XPIECES * 1024 <= X_BYTES, "halo region");
+    constexpr int STAGE = OFF_X + WCI * X_BYTES;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const unsigned lds0 = lds_addr(smem);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wco = wave & 3, wci = wave >> 2;
 
-    const int ncic = a.Cin / 32;
+    const int ncic = a.Cin / (32 * WCI);
     const int ks = blockIdx.x % a.ksplit;
     const int rest = blockIdx.x / a.ksplit;
-    const int ci0 = (rest % ncic) * 32, co0 = (rest / ncic) * 128;
+    const int ci0 = (rest % ncic) * 32 * WCI + 32 * wci, co0 = (rest / ncic) * 128;
     const bf16_t* X = (const bf16_t*)a.x;
     const bf16_t* DY = (const bf16_t*)a.dy;
     const int Hs = a.upsample ? a.H >> 1 : a.H, Ws = a.upsample ? a.W >> 1 : a.W;
@@ -81,20 +85,20 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs a) {
     // transposed-read lane roles: group g = lane>>4 -> channel half (g&1), pixel half h = g>>1;
     // inside the group lane 4q+pp addresses pixel q, channels 4pp..4pp+3
     const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3, h = g >> 1;
-    const int a_lchunk = 4 * wave + (g & 1) * 2 + (pp >> 1);            // 16-byte chunk of this wave's 32 channels
+    const int a_lchunk = 4 * wco + (g & 1) * 2 + (pp >> 1);            // 16-byte chunk of this wave's 32 channels
     const int a_off = ((a_lchunk ^ (q << 2)) << 4) + (pp & 1) * 8;      // chunk index XOR (pixel & 3) << 2
     const int b_off = (g & 1) * 32 + pp * 8;
     const int tpi = SW == 16 ? (a.H >> 2) * (a.W >> 4) : 1;             // tiles per image
     const int tpr = SW == 16 ? (a.W >> 4) : 1;
 
-    // dY copies: piece j*4+wave holds pixels 16j + pl, pl = 4*wave + lane/16; chunk c of pixel p holds logical
-    // chunk c ^ ((p&3)<<2)
+    // dY copies, shared by all waves: piece j*4*WCI + wave holds pixels 16*WCI*j + pl, pl = 4*wave + lane/16;
+    // chunk c of pixel p holds logical chunk c ^ ((p&3)<<2)
     const int pl = 4 * wave + (lane >> 4);
-    const int y_px = SW == 16 ? pl : (pl & 7), y_py = SW == 16 ? 0 : (pl >> 3);
+    const int y_px = pl % SW, y_py = pl / SW;
     const int y_co = co0 + (((lane & 15) ^ ((pl & 3) << 2)) << 3);
     const bool y_ok = y_co < a.Cout;                                      // Cout is a multiple of 8
     const int y_lane_off = (y_py * a.W + y_px) * a.Cout + y_co;
-    const int y_piece_stride = (SW == 16 ? 1 : 2) * a.W * a.Cout;         // rows 16 (or 8+8) pixels apart
+    const int y_piece_stride = (16 * WCI / SW) * a.W * a.Cout;            // 16*WCI pixels = this many rows
 
     auto stage = [&](int tile, int buf) {
         int b0, y0, x0;
@@ -103,14 +107,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs a) {
         const unsigned base = lds0 + buf * STAGE;
         const bf16_t* ytile = DY + ((size_t)(b0 * a.H + y0) * a.W + x0) * a.Cout + y_lane_off;
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < 4 / WCI; ++j)
             glds16(pick_ptr(y_ok, ytile + (size_t)j * y_piece_stride, g_zero_page),
-                   __builtin_amdgcn_readfirstlane(base + (j * 4 + wave) * 1024));
-        // X halo: pieces of 16 halo pixels x 64 bytes
+                   __builtin_amdgcn_readfirstlane(base + (j * 4 * WCI + wave) * 1024));
+        // X halo of this wave's ci group (copied by its four waves): pieces of 16 halo pixels x 64 bytes
         const bf16_t* ximg = X + (size_t)b0 * Hs * Ws * a.Cin + ci0 + (lane & 3) * 8;
 #pragma unroll
         for (int j = 0; j < (XPIECES + 3) / 4; ++j) {
-            const int piece = j * 4 + wave;
+            const int piece = j * 4 + wco;
             const unsigned hp = piece * 16 + (lane >> 2);
             const unsigned hy = hp / HPW, hx = hp - hy * HPW;
             const int yy = y0 + (int)hy - PAD, xx = x0 + (int)hx - PAD;
@@ -118,7 +122,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs a) {
             const int sy = a.upsample ? yy >> 1 : yy, sx = a.upsample ? xx >> 1 : xx;
             if (XPIECES % 4 == 0 || piece < XPIECES)                      // wave-uniform
                 glds16(pick_ptr(ok, ximg + (sy * Ws + sx) * a.Cin, g_zero_page),
-                       __builtin_amdgcn_readfirstlane(base + OFF_X + piece * 1024));
+                       __builtin_amdgcn_readfirstlane(base + OFF_X + wci * X_BYTES + piece * 1024));
         }
     };
 
@@ -127,9 +131,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs a) {
     for (int tile = ks; tile < a.ntiles; tile += a.ksplit) {
         dma_wait_all();
         __syncthreads();                     // this tile has landed and the other stage has been consumed
-        if (tile + a.ksplit < a.ntiles) stage(tile + a.ksplit, buf ^ 1);
+        if (tile + a.ksplit < a.ntiles && !(a.dbg & 1)) stage(tile + a.ksplit, buf ^ 1);
+        if (a.dbg & 2) { buf ^= 1; continue; }
         const unsigned char* ys = smem + buf * STAGE;
-        const unsigned char* xs = ys + OFF_X;
+        const unsigned char* xs = ys + OFF_X + wci * X_BYTES;
         // The shifted-X operand of tap row ky at step s covers halo rows RS*s + ky (and the next one when a step
         // is two image rows): the operand of (s, ky) is the operand of (s + 1, ky - RS), so it is read from LDS
         // once and kept in registers until its last use.
@@ -162,7 +167,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs a) {
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-            const int co = co0 + 32 * wave + acc_row(e, lane);
+            const int co = co0 + 32 * wco + acc_row(e, lane);
             if (co < a.Cout) out[((size_t)co * NT + t) * a.Cin + ci0 + (lane & 31)] = acc[t][e];
         }
 }
@@ -320,11 +325,9 @@ __global__ void wgrad_edge_reduce_kernel(const float* partial, float* dw, int ns
     dw[o] = accumulate ? dw[o] + s : s;
 }
 
-// Two workgroups are resident per CU (256 CUs): one full round of the chip, since a second, partly filled
+// `slots` workgroups are resident on the chip (256 CUs): one full round, since a second, partly filled
 // round would idle CUs and every extra split adds a partial buffer to write and reduce.
-static int pick_ksplit(int slices, int ntiles) {
-    const char* e = getenv("MAD_WGRAD_SLOTS");
-    const int slots = e ? atoi(e) : 512;
+static int pick_ksplit(int slices, int ntiles, int slots) {
     int k = slots / slices;
     if (k > ntiles) k = ntiles;
     if (k > 256) k = 256;
@@ -341,11 +344,19 @@ static bool wgrad_mfma_ok(int dtype, int H, int W, int Cin, int Cout, int ksize)
     return H % 8 == 0 && W % 16 == 0;
 }
 
+// ci groups per workgroup of the MFMA kernel
+static int wgrad_wci(int Cin) {
+    const char* e = getenv("MAD_WGRAD_WCI");
+    if (e && e[0] == '1') return 1;
+    return Cin % 64 == 0 ? 2 : 1;
+}
+
 static int wgrad_ksplit(int dtype, int B, int H, int W, int Cin, int Cout, int ksize, int* ntiles_out) {
     if (wgrad_mfma_ok(dtype, H, W, Cin, Cout, ksize)) {
         const int ntiles = (H == 8 && W == 8) ? B : B * (H / 4) * (W / 16);
         if (ntiles_out) *ntiles_out = ntiles;
-        return pick_ksplit(((Cout + 127) / 128) * (Cin / 32), ntiles);
+        const int wci = wgrad_wci(Cin);
+        return pick_ksplit(((Cout + 127) / 128) * (Cin / (32 * wci)), ntiles, 512 / wci);
     }
     if (ntiles_out) *ntiles_out = 0;
     int k = (1024 + Cout * ksize * ksize - 1) / (Cout * ksize * ksize);
@@ -375,9 +386,17 @@ extern "C" int mad_conv_wgrad(const void* x, const void* dy, float* dw, void* wo
         WgradArgs a;
         a.x = x; a.dy = dy; a.partial = (float*)workspace; a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
         a.ksplit = ksplit; a.ntiles = ntiles; a.upsample = upsample;
-        const dim3 grid(((Cout + 127) / 128) * (Cin / 32) * ksplit);
+        { const char* e = getenv("MAD_WGRAD_DBG"); a.dbg = e ? atoi(e) : 0; }
+        const int wci = wgrad_wci(Cin);
+        const dim3 grid(((Cout + 127) / 128) * (Cin / (32 * wci)) * ksplit);
         const bool small = H == 8 && W == 8;
-#define MAD_WG_LAUNCH(KS, SW) hipLaunchKernelGGL((wgrad_mfma_kernel<KS, SW>), grid, dim3(256), wg::LDS_BYTES, s, a)
+#define MAD_WG_LAUNCH(KS, SW)                                                                                        \
+    do {                                                                                                             \
+        if (wci == 2)                                                                                                \
+            hipLaunchKernelGGL((wgrad_mfma_kernel<KS, SW, 2>), grid, dim3(512), 2 * (wg::OFF_X + 2 * wg::X_BYTES), s, a); \
+        else                                                                                                         \
+            hipLaunchKernelGGL((wgrad_mfma_kernel<KS, SW, 1>), grid, dim3(256), 2 * (wg::OFF_X + wg::X_BYTES), s, a); \
+    } while (0)
         if (ksize == 3) { if (small) MAD_WG_LAUNCH(3, 8); else MAD_WG_LAUNCH(3, 16); }
         else { if (small) MAD_WG_LAUNCH(1, 8); else MAD_WG_LAUNCH(1, 16); }
 #undef MAD_WG_LAUNCH
