@@ -19,17 +19,16 @@ namespace mad {
 
 struct WgradArgs {
     const void* x; const void* dy; float* partial;
-    int B, H, W, Cin, Cout, ksplit, ntiles, upsample, dbg;
+    int B, H, W, Cin, Cout, ksplit, ntiles, upsample;
 };
 
 namespace wg {
-constexpr int TPIX = 64;                   // pixels per tile
 constexpr int YROW = 256;                  // bytes of dY per pixel in LDS: 128 bf16 output channels
 constexpr int XROW = 64;                   // bytes of X per halo pixel in LDS: 32 bf16 input channels
-constexpr int OFF_X = TPIX * YROW;         // 16 KiB
-constexpr int X_BYTES = 7 * 1024;          // up to 112 halo pixels
-// the X region of a workgroup with WCI groups of input channels is WCI * X_BYTES; two stages are resident:
-// the tile being multiplied and the tile being copied
+// LDS of a workgroup with WCI groups of 32 input channels: two stages (the tile being multiplied and the tile
+// being copied) of 64*WCI pixels of dY and WCI halo regions of up to 112 (WCI 1) or 208 (WCI 2) pixels
+constexpr int x_bytes(int wci) { return wci == 1 ? 7 * 1024 : 13 * 1024; }
+constexpr int lds_bytes(int wci) { return 2 * (64 * wci * YROW + wci * x_bytes(wci)); }
 }  // namespace wg
 
 typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
@@ -47,21 +46,22 @@ __device__ __forceinline__ const void* pick_ptr(bool ok, const void* p, const vo
     return (const void*)(((uintptr_t)p & m) | ((uintptr_t)other & ~m));
 }
 
-// KS: 1 or 3.  SW: 16 = a tile is 4 rows x 16 columns of one image (H % 4 == 0, W % 16 == 0);
-//              8 = a tile is one whole 8x8 image.
+// KS: 1 or 3.  A tile is TS = 4*WCI steps of 16 pixels.  SW: 16 = TS rows x 16 columns of one image
+// (H % TS == 0, W % 16 == 0); 8 = TS/4 whole 8x8 images (consecutive images are consecutive rows).
 // Two tiles are resident: the copies of the next tile are issued right after the barrier that hands over the
 // current one and land while it is multiplied.  A dY piece's pixel is (compile-time piece row) + (per-lane
 // pixel), so its address is a per-lane offset plus scalars.
-// WCI: 1 = four waves, a 128 x 32 slice, two workgroups per CU; 2 = eight waves (wave = (ci group, co group)),
-// a 128 x 64 slice, one workgroup per CU: the dY tile is copied once for both ci groups and half as many
-// partial sums are written.
+// WCI: 1 = four waves, a 128 x 32 slice, 64-pixel tiles, two workgroups per CU; 2 = eight waves (wave = (ci group,
+// co group)), a 128 x 64 slice, 128-pixel tiles, one workgroup per CU: the dY tile is copied once for both ci
+// groups, half as many partial sums are written and half as many barriers are passed.
 template <int KS, int SW, int WCI>
 __global__ __launch_bounds__(256 * WCI, 2 / WCI) void wgrad_mfma_kernel(WgradArgs a) {
     using namespace wg;
-    constexpr int PAD = KS / 2, NT = KS * KS;
-    constexpr int SH = SW == 16 ? 4 : 8;
-    constexpr int HPW = SW + 2 * PAD, HPH = SH + 2 * PAD, HPIX = HPH * HPW;
+    constexpr int PAD = KS / 2, NT = KS * KS, TS = 4 * WCI, TPIX = 16 * TS;
+    constexpr int NIMG = SW == 16 ? 1 : (TS + 3) / 4, SH = SW == 16 ? TS : 8;
+    constexpr int HPW = SW + 2 * PAD, HPH = SH + 2 * PAD, HPIX = NIMG * HPH * HPW;
     constexpr int XPIECES = (HPIX + 15) / 16;
+    constexpr int OFF_X = TPIX * YROW, X_BYTES = x_bytes(WCI);
     static_assert(XPIECES * 1024 <= X_BYTES, "halo region");
     constexpr int STAGE = OFF_X + WCI * X_BYTES;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256 * WCI, 2 / WCI) void wgrad_mfma_kernel(WgradArg
     const int a_lchunk = 4 * wco + (g & 1) * 2 + (pp >> 1);            // 16-byte chunk of this wave's 32 channels
     const int a_off = ((a_lchunk ^ (q << 2)) << 4) + (pp & 1) * 8;      // chunk index XOR (pixel & 3) << 2
     const int b_off = (g & 1) * 32 + pp * 8;
-    const int tpi = SW == 16 ? (a.H >> 2) * (a.W >> 4) : 1;             // tiles per image
+    const int tpi = SW == 16 ? (a.H / TS) * (a.W >> 4) : 1;             // tiles per image
     const int tpr = SW == 16 ? (a.W >> 4) : 1;
 
     // dY copies, shared by all waves: piece j*4*WCI + wave holds pixels 16*WCI*j + pl, pl = 4*wave + lane/16;
@@ -102,24 +102,28 @@ __global__ __launch_bounds__(256 * WCI, 2 / WCI) void wgrad_mfma_kernel(WgradArg
 
     auto stage = [&](int tile, int buf) {
         int b0, y0, x0;
-        if (SW == 16) { b0 = tile / tpi; const int r = tile - b0 * tpi; y0 = (r / tpr) * 4; x0 = (r % tpr) * 16; }
-        else { b0 = tile; y0 = 0; x0 = 0; }
+        if (SW == 16) { b0 = tile / tpi; const int r = tile - b0 * tpi; y0 = (r / tpr) * TS; x0 = (r % tpr) * 16; }
+        else { b0 = tile * NIMG; y0 = 0; x0 = 0; }
         const unsigned base = lds0 + buf * STAGE;
         const bf16_t* ytile = DY + ((size_t)(b0 * a.H + y0) * a.W + x0) * a.Cout + y_lane_off;
 #pragma unroll
-        for (int j = 0; j < 4 / WCI; ++j)
-            glds16(pick_ptr(y_ok, ytile + (size_t)j * y_piece_stride, g_zero_page),
+        for (int j = 0; j < TPIX / (16 * WCI); ++j) {
+            const bool img_ok = NIMG == 1 || b0 + (16 * WCI * j) / 64 < a.B;   // SW 8: pixel 16*WCI*j is in image ../64
+            glds16(pick_ptr(y_ok & img_ok, ytile + (size_t)j * y_piece_stride, g_zero_page),
                    __builtin_amdgcn_readfirstlane(base + (j * 4 * WCI + wave) * 1024));
+        }
         // X halo of this wave's ci group (copied by its four waves): pieces of 16 halo pixels x 64 bytes
         const bf16_t* ximg = X + (size_t)b0 * Hs * Ws * a.Cin + ci0 + (lane & 3) * 8;
 #pragma unroll
         for (int j = 0; j < (XPIECES + 3) / 4; ++j) {
             const int piece = j * 4 + wco;
             const unsigned hp = piece * 16 + (lane >> 2);
-            const unsigned hy = hp / HPW, hx = hp - hy * HPW;
+            const unsigned img = NIMG == 1 ? 0u : (hp >= (unsigned)(HPH * HPW) ? 1u : 0u), r = hp - img * (HPH * HPW);
+            const unsigned hy = r / HPW, hx = r - hy * HPW;
             const int yy = y0 + (int)hy - PAD, xx = x0 + (int)hx - PAD;
-            const bool ok = (hp < (unsigned)HPIX) & ((unsigned)yy < (unsigned)a.H) & ((unsigned)xx < (unsigned)a.W);
-            const int sy = a.upsample ? yy >> 1 : yy, sx = a.upsample ? xx >> 1 : xx;
+            const bool ok = (hp < (unsigned)HPIX) & ((unsigned)yy < (unsigned)a.H) & ((unsigned)xx < (unsigned)a.W) &
+                            (b0 + (int)img < a.B);
+            const int sy = (a.upsample ? yy >> 1 : yy) + (int)img * Hs, sx = a.upsample ? xx >> 1 : xx;
             if (XPIECES % 4 == 0 || piece < XPIECES)                      // wave-uniform
                 glds16(pick_ptr(ok, ximg + (sy * Ws + sx) * a.Cin, g_zero_page),
                        __builtin_amdgcn_readfirstlane(base + OFF_X + wci * X_BYTES + piece * 1024));
@@ -131,23 +135,22 @@ __global__ __launch_bounds__(256 * WCI, 2 / WCI) void wgrad_mfma_kernel(WgradArg
     for (int tile = ks; tile < a.ntiles; tile += a.ksplit) {
         dma_wait_all();
         __syncthreads();                     // this tile has landed and the other stage has been consumed
-        if (tile + a.ksplit < a.ntiles && !(a.dbg & 1)) stage(tile + a.ksplit, buf ^ 1);
-        if (a.dbg & 2) { buf ^= 1; continue; }
+        if (tile + a.ksplit < a.ntiles) stage(tile + a.ksplit, buf ^ 1);
         const unsigned char* ys = smem + buf * STAGE;
         const unsigned char* xs = ys + OFF_X + wci * X_BYTES;
-        // The shifted-X operand of tap row ky at step s covers halo rows RS*s + ky (and the next one when a step
-        // is two image rows): the operand of (s, ky) is the operand of (s + 1, ky - RS), so it is read from LDS
-        // once and kept in registers until its last use.
-        constexpr int RS = SW == 16 ? 1 : 2;
-        bf16x8 xf[3 * RS + KS][KS];
+        // The shifted-X operand of tap row ky at step s covers halo row rowid(s, ky) (and the next one when a step
+        // is two image rows).  Consecutive steps share halo rows, so an operand is read from LDS at its first
+        // use and kept in registers until its last.
+        auto rowid = [](int s, int ky) { return SW == 16 ? s + ky : (s >> 2) * HPH + 2 * (s & 3) + ky; };
+        bf16x8 xf[NIMG * HPH][KS];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
+        for (int s = 0; s < TS; ++s) {
             const int pa = 16 * s + 4 * h + q;                           // tile pixel of the low half
             const bf16x8 af = tr_frag(ys + pa * YROW + a_off, ys + (pa + 8) * YROW + a_off);
 #pragma unroll
             for (int ky = 0; ky < KS; ++ky) {
-                const int R = RS * s + ky;
-                if (s == 0 || R > RS * (s - 1) + KS - 1) {               // first use of halo row R
+                const int R = rowid(s, ky);
+                if (s == 0 || R > rowid(s - 1, KS - 1)) {                // first use of halo row R
 #pragma unroll
                     for (int kx = 0; kx < KS; ++kx) {
                         const int hp_lo = R * HPW + kx + 4 * h + q, hp_hi = hp_lo + (SW == 16 ? 8 : HPW);
@@ -353,9 +356,9 @@ static int wgrad_wci(int Cin) {
 
 static int wgrad_ksplit(int dtype, int B, int H, int W, int Cin, int Cout, int ksize, int* ntiles_out) {
     if (wgrad_mfma_ok(dtype, H, W, Cin, Cout, ksize)) {
-        const int ntiles = (H == 8 && W == 8) ? B : B * (H / 4) * (W / 16);
-        if (ntiles_out) *ntiles_out = ntiles;
         const int wci = wgrad_wci(Cin);
+        const int ntiles = (H == 8 && W == 8) ? (B + wci - 1) / wci : B * (H / (4 * wci)) * (W / 16);
+        if (ntiles_out) *ntiles_out = ntiles;
         return pick_ksplit(((Cout + 127) / 128) * (Cin / (32 * wci)), ntiles, 512 / wci);
     }
     if (ntiles_out) *ntiles_out = 0;
@@ -386,16 +389,24 @@ extern "C" int mad_conv_wgrad(const void* x, const void* dy, float* dw, void* wo
         WgradArgs a;
         a.x = x; a.dy = dy; a.partial = (float*)workspace; a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
         a.ksplit = ksplit; a.ntiles = ntiles; a.upsample = upsample;
-        { const char* e = getenv("MAD_WGRAD_DBG"); a.dbg = e ? atoi(e) : 0; }
         const int wci = wgrad_wci(Cin);
         const dim3 grid(((Cout + 127) / 128) * (Cin / (32 * wci)) * ksplit);
         const bool small = H == 8 && W == 8;
 #define MAD_WG_LAUNCH(KS, SW)                                                                                        \
     do {                                                                                                             \
-        if (wci == 2)                                                                                                \
-            hipLaunchKernelGGL((wgrad_mfma_kernel<KS, SW, 2>), grid, dim3(512), 2 * (wg::OFF_X + 2 * wg::X_BYTES), s, a); \
-        else                                                                                                         \
-            hipLaunchKernelGGL((wgrad_mfma_kernel<KS, SW, 1>), grid, dim3(256), 2 * (wg::OFF_X + wg::X_BYTES), s, a); \
+        if (wci == 2) {                                                                                              \
+            static bool big_lds = false;                                                                             \
+            if (!big_lds) {                                                                                          \
+                MAD_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_mfma_kernel<KS, SW, 2>),        \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize,                          \
+                                                wg::lds_bytes(2)) == hipSuccess,                                     \
+                            "mad_conv_wgrad: cannot raise the dynamic LDS limit");                                   \
+                big_lds = true;                                                                                      \
+            }                                                                                                        \
+            hipLaunchKernelGGL((wgrad_mfma_kernel<KS, SW, 2>), grid, dim3(512), wg::lds_bytes(2), s, a);             \
+        } else {                                                                                                     \
+            hipLaunchKernelGGL((wgrad_mfma_kernel<KS, SW, 1>), grid, dim3(256), wg::lds_bytes(1), s, a);             \
+        }                                                                                                            \
     } while (0)
         if (ksize == 3) { if (small) MAD_WG_LAUNCH(3, 8); else MAD_WG_LAUNCH(3, 16); }
         else { if (small) MAD_WG_LAUNCH(1, 8); else MAD_WG_LAUNCH(1, 16); }
