@@ -26,8 +26,8 @@ namespace wg {
 constexpr int YROW = 256;                  // bytes of dY per pixel in LDS: 128 bf16 output channels
 constexpr int XROW = 64;                   // bytes of X per halo pixel in LDS: 32 bf16 input channels
 // LDS of a workgroup with WCI groups of 32 input channels: two stages (the tile being multiplied and the tile
-// being copied) of 64*WCI pixels of dY and WCI halo regions of up to 112 (WCI 1) or 208 (WCI 2) pixels
-constexpr int x_bytes(int wci) { return wci == 1 ? 7 * 1024 : 13 * 1024; }
+// being copied) of 64*WCI pixels of dY and WCI halo regions of up to 128 (WCI 1) or 256 (WCI 2) pixels
+constexpr int x_bytes(int wci) { return wci == 1 ? 8 * 1024 : 16 * 1024; }    // whole rounds of four pieces
 constexpr int lds_bytes(int wci) { return 2 * (64 * wci * YROW + wci * x_bytes(wci)); }
 }  // namespace wg
 
@@ -100,42 +100,54 @@ __global__ __launch_bounds__(256 * WCI, 2 / WCI) void wgrad_mfma_kernel(WgradArg
     const int y_lane_off = (y_py * a.W + y_px) * a.Cout + y_co;
     const int y_piece_stride = (16 * WCI / SW) * a.W * a.Cout;            // 16*WCI pixels = this many rows
 
-    auto stage = [&](int tile, int buf) {
-        int b0, y0, x0;
-        if (SW == 16) { b0 = tile / tpi; const int r = tile - b0 * tpi; y0 = (r / tpr) * TS; x0 = (r % tpr) * 16; }
-        else { b0 = tile * NIMG; y0 = 0; x0 = 0; }
+    // The copies of a tile are issued in NPART parts, one per multiply step, so that the waves of a SIMD do not
+    // all sit in copy issue at the same time.  Part `part` (compile-time) is one dY piece or one X piece per
+    // wave; `live` false (no next tile) turns every read into a read of the zero page.
+    constexpr int YPARTS = TPIX / (16 * WCI), XPARTS = (XPIECES + 3) / 4, NPART = YPARTS + XPARTS;
+    struct Origin { int b0, y0, x0; };
+    auto origin = [&](int tile) {
+        Origin o;
+        if (SW == 16) { o.b0 = tile / tpi; const int r = tile - o.b0 * tpi; o.y0 = (r / tpr) * TS; o.x0 = (r % tpr) * 16; }
+        else { o.b0 = tile * NIMG; o.y0 = 0; o.x0 = 0; }
+        return o;
+    };
+    auto stage_part = [&](const Origin& o, bool live, int buf, int part) {
         const unsigned base = lds0 + buf * STAGE;
-        const bf16_t* ytile = DY + ((size_t)(b0 * a.H + y0) * a.W + x0) * a.Cout + y_lane_off;
-#pragma unroll
-        for (int j = 0; j < TPIX / (16 * WCI); ++j) {
-            const bool img_ok = NIMG == 1 || b0 + (16 * WCI * j) / 64 < a.B;   // SW 8: pixel 16*WCI*j is in image ../64
-            glds16(pick_ptr(y_ok & img_ok, ytile + (size_t)j * y_piece_stride, g_zero_page),
+        if (part < YPARTS) {
+            const int j = part;
+            const bf16_t* src = DY + ((size_t)(o.b0 * a.H + o.y0) * a.W + o.x0) * a.Cout + y_lane_off +
+                                (size_t)j * y_piece_stride;
+            const bool img_ok = NIMG == 1 || o.b0 + (16 * WCI * j) / 64 < a.B;   // SW 8: the image of pixel 16*WCI*j
+            glds16(pick_ptr(live & y_ok & img_ok, src, g_zero_page),
                    __builtin_amdgcn_readfirstlane(base + (j * 4 * WCI + wave) * 1024));
-        }
-        // X halo of this wave's ci group (copied by its four waves): pieces of 16 halo pixels x 64 bytes
-        const bf16_t* ximg = X + (size_t)b0 * Hs * Ws * a.Cin + ci0 + (lane & 3) * 8;
-#pragma unroll
-        for (int j = 0; j < (XPIECES + 3) / 4; ++j) {
-            const int piece = j * 4 + wco;
+        } else if (part < NPART) {
+            // X halo of this wave's ci group (copied by its four waves): pieces of 16 halo pixels x 64 bytes;
+            // pieces past the halo exist in LDS and are filled with zeros
+            const int piece = (part - YPARTS) * 4 + wco;
             const unsigned hp = piece * 16 + (lane >> 2);
             const unsigned img = NIMG == 1 ? 0u : (hp >= (unsigned)(HPH * HPW) ? 1u : 0u), r = hp - img * (HPH * HPW);
             const unsigned hy = r / HPW, hx = r - hy * HPW;
-            const int yy = y0 + (int)hy - PAD, xx = x0 + (int)hx - PAD;
-            const bool ok = (hp < (unsigned)HPIX) & ((unsigned)yy < (unsigned)a.H) & ((unsigned)xx < (unsigned)a.W) &
-                            (b0 + (int)img < a.B);
+            const int yy = o.y0 + (int)hy - PAD, xx = o.x0 + (int)hx - PAD;
+            const bool ok = live & (hp < (unsigned)HPIX) & ((unsigned)yy < (unsigned)a.H) &
+                            ((unsigned)xx < (unsigned)a.W) & (o.b0 + (int)img < a.B);
             const int sy = (a.upsample ? yy >> 1 : yy) + (int)img * Hs, sx = a.upsample ? xx >> 1 : xx;
-            if (XPIECES % 4 == 0 || piece < XPIECES)                      // wave-uniform
-                glds16(pick_ptr(ok, ximg + (sy * Ws + sx) * a.Cin, g_zero_page),
-                       __builtin_amdgcn_readfirstlane(base + OFF_X + wci * X_BYTES + piece * 1024));
+            const bf16_t* src = X + (size_t)o.b0 * Hs * Ws * a.Cin + ci0 + (lane & 3) * 8 + (sy * Ws + sx) * a.Cin;
+            glds16(pick_ptr(ok, src, g_zero_page),
+                   __builtin_amdgcn_readfirstlane(base + OFF_X + wci * X_BYTES + piece * 1024));
         }
     };
 
     int buf = 0;
-    if (ks < a.ntiles) stage(ks, 0);
+    if (ks < a.ntiles) {
+        const Origin o = origin(ks);
+#pragma unroll
+        for (int part = 0; part < NPART; ++part) stage_part(o, true, 0, part);
+    }
     for (int tile = ks; tile < a.ntiles; tile += a.ksplit) {
         dma_wait_all();
         __syncthreads();                     // this tile has landed and the other stage has been consumed
-        if (tile + a.ksplit < a.ntiles) stage(tile + a.ksplit, buf ^ 1);
+        const bool more = tile + a.ksplit < a.ntiles;
+        const Origin nxt = origin(more ? tile + a.ksplit : tile);
         const unsigned char* ys = smem + buf * STAGE;
         const unsigned char* xs = ys + OFF_X + wci * X_BYTES;
         // The shifted-X operand of tap row ky at step s covers halo row rowid(s, ky) (and the next one when a step
@@ -147,6 +159,8 @@ __global__ __launch_bounds__(256 * WCI, 2 / WCI) void wgrad_mfma_kernel(WgradArg
         for (int s = 0; s < TS; ++s) {
             const int pa = 16 * s + 4 * h + q;                           // tile pixel of the low half
             const bf16x8 af = tr_frag(ys + pa * YROW + a_off, ys + (pa + 8) * YROW + a_off);
+#pragma unroll
+            for (int part = s * NPART / TS; part < (s + 1) * NPART / TS; ++part) stage_part(nxt, more, buf ^ 1, part);
 #pragma unroll
             for (int ky = 0; ky < KS; ++ky) {
                 const int R = rowid(s, ky);
