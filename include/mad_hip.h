@@ -241,6 +241,14 @@ int mad_conv_wgrad(const void* x, const void* dy, float* dw, void* workspace, si
                    int dtype, int B, int H, int W, int Cin, int Cout, int ksize, int upsample,
                    int accumulate, void* stream);
 
+/* mad_conv_wgrad that also produces the bias gradient dbias[co] (+)= sum_{b,y,x} dy[b,y,x,co] (fp32 (Cout,),
+ * may be null) from the same pass over dy: on the MFMA path it is the weight gradient of an input channel of
+ * ones, elsewhere a column sum.  Same workspace as mad_conv_wgrad.
+ * Autograd of Conv2d.forward (model.py:135-166) with respect to `weight` and `bias`. */
+int mad_conv_wgrad_bias(const void* x, const void* dy, float* dw, float* dbias, void* workspace,
+                        size_t workspace_bytes, int dtype, int B, int H, int W, int Cin, int Cout, int ksize,
+                        int upsample, int accumulate, int bias_accumulate, void* stream);
+
 /* dbias[c] (+)= sum over rows of dy (rows, C): the bias gradient of a convolution or linear layer
  * (model.py:164-165, 62-63). */
 size_t mad_bias_grad_workspace(int C);

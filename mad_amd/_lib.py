@@ -56,6 +56,8 @@ SIGNATURES = {
                                  c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "mad_conv_wgrad_workspace": (ctypes.c_size_t, [c_int] * 7),
     "mad_conv_wgrad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_size_t] + [c_int] * 9 + [c_void_p]),
+    "mad_conv_wgrad_bias": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_size_t] + [c_int] * 10 +
+                            [c_void_p]),
     "mad_bias_grad_workspace": (ctypes.c_size_t, [c_int]),
     "mad_bias_grad": (c_int, [c_void_p, c_int, ctypes.c_long, c_int, c_void_p, c_void_p, ctypes.c_size_t, c_int, c_void_p]),
     "mad_gn_bwd_partial": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, ctypes.c_ulonglong,

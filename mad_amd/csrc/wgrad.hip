@@ -19,6 +19,7 @@ namespace mad {
 
 struct WgradArgs {
     const void* x; const void* dy; float* partial;
+    float* bias_partial;                      // [ksplit][Cout] column sums of dY, or null
     int B, H, W, Cin, Cout, ksplit, ntiles, upsample;
 };
 
@@ -54,7 +55,8 @@ __device__ __forceinline__ const void* pick_ptr(bool ok, const void* p, const vo
 // WCI: 1 = four waves, a 128 x 32 slice, 64-pixel tiles, two workgroups per CU; 2 = eight waves (wave = (ci group,
 // co group)), a 128 x 64 slice, 128-pixel tiles, one workgroup per CU: the dY tile is copied once for both ci
 // groups, half as many partial sums are written and half as many barriers are passed.
-template <int KS, int SW, int WCI>
+// BIAS: also produce the column sums of dY.
+template <int KS, int SW, int WCI, bool BIAS>
 __global__ __launch_bounds__(256 * WCI, 2 / WCI) void wgrad_mfma_kernel(WgradArgs a) {
     using namespace wg;
     constexpr int PAD = KS / 2, NT = KS * KS, TS = 4 * WCI, TPIX = 16 * TS;
@@ -81,6 +83,14 @@ __global__ __launch_bounds__(256 * WCI, 2 / WCI) void wgrad_mfma_kernel(WgradArg
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[t][e] = 0.0f;
+    // The bias gradient (column sums of dY) is the weight gradient of an input channel of ones: the waves of the
+    // first ci group of the first ci slice add one MFMA per step with an all-ones B operand.
+    const bool with_bias = BIAS && rest % ncic == 0 && wci == 0;
+    f32x16 accb;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) accb[e] = 0.0f;
+    const __bf16 one_bf = (__bf16)1.0f;
+    const bf16x8 ones = {one_bf, one_bf, one_bf, one_bf, one_bf, one_bf, one_bf, one_bf};
 
     // transposed-read lane roles: group g = lane>>4 -> channel half (g&1), pixel half h = g>>1;
     // inside the group lane 4q+pp addresses pixel q, channels 4pp..4pp+3
@@ -161,6 +171,7 @@ __global__ __launch_bounds__(256 * WCI, 2 / WCI) void wgrad_mfma_kernel(WgradArg
             const bf16x8 af = tr_frag(ys + pa * YROW + a_off, ys + (pa + 8) * YROW + a_off);
 #pragma unroll
             for (int part = s * NPART / TS; part < (s + 1) * NPART / TS; ++part) stage_part(nxt, more, buf ^ 1, part);
+            if (BIAS && with_bias) accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, ones, accb, 0, 0, 0);
 #pragma unroll
             for (int ky = 0; ky < KS; ++ky) {
                 const int R = rowid(s, ky);
@@ -187,6 +198,13 @@ __global__ __launch_bounds__(256 * WCI, 2 / WCI) void wgrad_mfma_kernel(WgradArg
             const int co = co0 + 32 * wco + acc_row(e, lane);
             if (co < a.Cout) out[((size_t)co * NT + t) * a.Cin + ci0 + (lane & 31)] = acc[t][e];
         }
+    if (BIAS && with_bias && (lane & 31) == 0) {                  // every column of accb holds the same sums
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int co = co0 + 32 * wco + acc_row(e, lane);
+            if (co < a.Cout) a.bias_partial[(size_t)ks * a.Cout + co] = accb[e];
+        }
+    }
 }
 
 // Generic (any channel counts, fp32 or bf16, strided operands) weight gradient on the vector ALU: the
@@ -242,9 +260,17 @@ __global__ void wgrad_reduce_kernel(const float* partial, float* dst, size_t n, 
 // One workgroup = one output channel x 32 input channels; the block is transposed through LDS so both
 // sides stay coalesced.  grid (Cout, ceil(Cin/32)).
 __global__ __launch_bounds__(288) void wgrad_reduce_oihw_kernel(const float* partial, float* dst, int Cout, int nsplit,
-                                                                 int accumulate, int taps, int Cin) {
+                                                                 int accumulate, int taps, int Cin,
+                                                                 const float* bias_partial, float* dbias,
+                                                                 int bias_accumulate) {
     __shared__ float blk[9 * 32];                         // [taps][32]
     const int co = blockIdx.x, c0 = blockIdx.y * 32;
+    if (bias_partial != nullptr && blockIdx.y == 0 && threadIdx.x < 64) {      // wave 0: dbias[co], fixed order
+        float sb = 0.0f;
+        for (int k = threadIdx.x; k < nsplit; k += 64) sb += bias_partial[(size_t)k * Cout + co];
+        for (int off = 32; off > 0; off >>= 1) sb += __shfl_down(sb, off, 64);
+        if (threadIdx.x == 0) dbias[co] = bias_accumulate ? dbias[co] + sb : sb;
+    }
     const int cw = Cin - c0 < 32 ? Cin - c0 : 32;
     const size_t n = (size_t)Cout * taps * Cin;
     const int t = threadIdx.x >> 5, cl = threadIdx.x & 31;
@@ -380,14 +406,29 @@ static int wgrad_ksplit(int dtype, int B, int H, int W, int Cin, int Cout, int k
     return k < 1 ? 1 : (k > 256 ? 256 : k);
 }
 
-extern "C" size_t mad_conv_wgrad_workspace(int dtype, int B, int H, int W, int Cin, int Cout, int ksize) {
-    const int k = wgrad_ksplit(dtype, B, H, W, Cin, Cout, ksize, nullptr);
+// partial sums of dW, then room for the partial sums of the bias gradient (either form)
+static size_t wgrad_main_bytes(int k, int Cin, int Cout, int ksize) {
     return (size_t)k * Cout * ksize * ksize * Cin * sizeof(float);
 }
+
+extern "C" size_t mad_conv_wgrad_workspace(int dtype, int B, int H, int W, int Cin, int Cout, int ksize) {
+    const int k = wgrad_ksplit(dtype, B, H, W, Cin, Cout, ksize, nullptr);
+    return wgrad_main_bytes(k, Cin, Cout, ksize) + (size_t)(k > 256 ? k : 256) * Cout * sizeof(float);
+}
+
+static int bias_grad_impl(const void* dy, int dtype, long rows, int C, float* dbias, float* workspace, int accumulate,
+                          hipStream_t s);
 
 extern "C" int mad_conv_wgrad(const void* x, const void* dy, float* dw, void* workspace, size_t workspace_bytes,
                               int dtype, int B, int H, int W, int Cin, int Cout, int ksize, int upsample,
                               int accumulate, void* stream) {
+    return mad_conv_wgrad_bias(x, dy, dw, nullptr, workspace, workspace_bytes, dtype, B, H, W, Cin, Cout, ksize,
+                               upsample, accumulate, 0, stream);
+}
+
+extern "C" int mad_conv_wgrad_bias(const void* x, const void* dy, float* dw, float* dbias, void* workspace,
+                                   size_t workspace_bytes, int dtype, int B, int H, int W, int Cin, int Cout,
+                                   int ksize, int upsample, int accumulate, int bias_accumulate, void* stream) {
     MAD_REQUIRE(x && dy && dw && workspace, "mad_conv_wgrad: null pointer");
     MAD_REQUIRE(dtype == MAD_BF16 || dtype == MAD_F32, "mad_conv_wgrad: bad dtype %d", dtype);
     MAD_REQUIRE(ksize == 1 || ksize == 3, "mad_conv_wgrad: ksize %d not supported", ksize);
@@ -399,32 +440,40 @@ extern "C" int mad_conv_wgrad(const void* x, const void* dy, float* dw, void* wo
     const int nt = ksize * ksize;
     int ntiles = 0;
     const int ksplit = wgrad_ksplit(dtype, B, H, W, Cin, Cout, ksize, &ntiles);
+    float* bias_ws = (float*)((char*)workspace + wgrad_main_bytes(ksplit, Cin, Cout, ksize));
+    const bool fused_bias = dbias && wgrad_mfma_ok(dtype, H, W, Cin, Cout, ksize);
     if (wgrad_mfma_ok(dtype, H, W, Cin, Cout, ksize)) {
         WgradArgs a;
         a.x = x; a.dy = dy; a.partial = (float*)workspace; a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
         a.ksplit = ksplit; a.ntiles = ntiles; a.upsample = upsample;
+        a.bias_partial = dbias ? bias_ws : nullptr;
         const int wci = wgrad_wci(Cin);
         const dim3 grid(((Cout + 127) / 128) * (Cin / (32 * wci)) * ksplit);
         const bool small = H == 8 && W == 8;
-#define MAD_WG_LAUNCH(KS, SW)                                                                                        \
+#define MAD_WG_LAUNCH2(KS, SW, BIAS)                                                                                 \
     do {                                                                                                             \
         if (wci == 2) {                                                                                              \
             static bool big_lds = false;                                                                             \
             if (!big_lds) {                                                                                          \
-                MAD_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_mfma_kernel<KS, SW, 2>),        \
+                MAD_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_mfma_kernel<KS, SW, 2, BIAS>),  \
                                                 hipFuncAttributeMaxDynamicSharedMemorySize,                          \
                                                 wg::lds_bytes(2)) == hipSuccess,                                     \
                             "mad_conv_wgrad: cannot raise the dynamic LDS limit");                                   \
                 big_lds = true;                                                                                      \
             }                                                                                                        \
-            hipLaunchKernelGGL((wgrad_mfma_kernel<KS, SW, 2>), grid, dim3(512), wg::lds_bytes(2), s, a);             \
+            hipLaunchKernelGGL((wgrad_mfma_kernel<KS, SW, 2, BIAS>), grid, dim3(512), wg::lds_bytes(2), s, a);       \
         } else {                                                                                                     \
-            hipLaunchKernelGGL((wgrad_mfma_kernel<KS, SW, 1>), grid, dim3(256), wg::lds_bytes(1), s, a);             \
+            hipLaunchKernelGGL((wgrad_mfma_kernel<KS, SW, 1, BIAS>), grid, dim3(256), wg::lds_bytes(1), s, a);       \
         }                                                                                                            \
+    } while (0)
+#define MAD_WG_LAUNCH(KS, SW)                                                                                        \
+    do {                                                                                                             \
+        if (fused_bias) MAD_WG_LAUNCH2(KS, SW, true); else MAD_WG_LAUNCH2(KS, SW, false);                            \
     } while (0)
         if (ksize == 3) { if (small) MAD_WG_LAUNCH(3, 8); else MAD_WG_LAUNCH(3, 16); }
         else { if (small) MAD_WG_LAUNCH(1, 8); else MAD_WG_LAUNCH(1, 16); }
 #undef MAD_WG_LAUNCH
+#undef MAD_WG_LAUNCH2
     } else {
         WgradGenArgs a;
         a.x = x; a.dy = dy; a.partial = (float*)workspace; a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
@@ -438,11 +487,32 @@ extern "C" int mad_conv_wgrad(const void* x, const void* dy, float* dw, void* wo
     }
     if (int rc = check_launch("mad_conv_wgrad")) return rc;
     hipLaunchKernelGGL(wgrad_reduce_oihw_kernel, dim3(Cout, (Cin + 31) / 32), dim3(288), 0, s,
-                       (const float*)workspace, dw, Cout, ksplit, accumulate, nt, Cin);
-    return check_launch("mad_conv_wgrad (reduce)");
+                       (const float*)workspace, dw, Cout, ksplit, accumulate, nt, Cin,
+                       fused_bias ? (const float*)bias_ws : (const float*)nullptr, dbias, bias_accumulate);
+    if (int rc = check_launch("mad_conv_wgrad (reduce)")) return rc;
+    if (dbias && !fused_bias) return bias_grad_impl(dy, dtype, (long)B * H * W, Cout, dbias, bias_ws, bias_accumulate, s);
+    return 0;
 }
 
 extern "C" size_t mad_bias_grad_workspace(int C) { return (size_t)256 * C * sizeof(float); }
+
+static int bias_grad_impl(const void* dy, int dtype, long rows, int C, float* dbias, float* workspace, int accumulate,
+                          hipStream_t s) {
+    // enough row shares to fill the chip for long inputs, few for short ones (the second pass adds them serially)
+    long want = rows / 64;
+    const int splits = (int)(want < 1 ? 1 : (want > 256 ? 256 : want));
+    const dim3 grid((C + 255) / 256, splits);
+    if (dtype == MAD_BF16)
+        hipLaunchKernelGGL((colsum_kernel<bf16_t>), grid, dim3(256), 0, s, (const bf16_t*)dy, workspace, rows, C, (long)C,
+                           1L);
+    else
+        hipLaunchKernelGGL((colsum_kernel<float>), grid, dim3(256), 0, s, (const float*)dy, workspace, rows, C, (long)C,
+                           1L);
+    if (int rc = check_launch("mad_bias_grad")) return rc;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((C + 255) / 256), dim3(256), 0, s, (const float*)workspace, dbias,
+                       (size_t)C, splits, accumulate, 0, 1);
+    return check_launch("mad_bias_grad (reduce)");
+}
 
 extern "C" int mad_bias_grad(const void* dy, int dtype, long rows, int C, float* dbias, void* workspace,
                              size_t workspace_bytes, int accumulate, void* stream) {
@@ -450,21 +520,7 @@ extern "C" int mad_bias_grad(const void* dy, int dtype, long rows, int C, float*
     MAD_REQUIRE(dtype == MAD_BF16 || dtype == MAD_F32, "mad_bias_grad: bad dtype %d", dtype);
     MAD_REQUIRE(rows > 0 && C > 0, "mad_bias_grad: bad shape");
     MAD_REQUIRE(workspace_bytes >= mad_bias_grad_workspace(C), "mad_bias_grad: workspace too small");
-    hipStream_t s = (hipStream_t)stream;
-    // enough row shares to fill the chip for long inputs, few for short ones (the second pass adds them serially)
-    long want = rows / 64;
-    const int splits = (int)(want < 1 ? 1 : (want > 256 ? 256 : want));
-    const dim3 grid((C + 255) / 256, splits);
-    if (dtype == MAD_BF16)
-        hipLaunchKernelGGL((colsum_kernel<bf16_t>), grid, dim3(256), 0, s, (const bf16_t*)dy, (float*)workspace, rows, C,
-                           (long)C, 1L);
-    else
-        hipLaunchKernelGGL((colsum_kernel<float>), grid, dim3(256), 0, s, (const float*)dy, (float*)workspace, rows, C,
-                           (long)C, 1L);
-    if (int rc = check_launch("mad_bias_grad")) return rc;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((C + 255) / 256), dim3(256), 0, s, (const float*)workspace, dbias,
-                       (size_t)C, splits, accumulate, 0, 1);
-    return check_launch("mad_bias_grad (reduce)");
+    return bias_grad_impl(dy, dtype, rows, C, dbias, (float*)workspace, accumulate, (hipStream_t)stream);
 }
 
 // First / last layer: operands in different dtypes and layouts (the image side is NCHW fp32).
@@ -525,6 +581,7 @@ extern "C" int mad_conv_wgrad_edge(const void* x, int x_dtype, int x_nchw, const
     else hipLaunchKernelGGL((wgrad_generic_kernel<bf16_t, bf16_t>), grid, dim3(256), 0, s, a);
     if (int rc = check_launch("mad_conv_wgrad_edge")) return rc;
     hipLaunchKernelGGL(wgrad_reduce_oihw_kernel, dim3(Cout, (Cin + 31) / 32), dim3(288), 0, s,
-                       (const float*)workspace, dw, Cout, ksplit, accumulate, nt, Cin);
+                       (const float*)workspace, dw, Cout, ksplit, accumulate, nt, Cin, (const float*)nullptr,
+                       (float*)nullptr, 0);
     return check_launch("mad_conv_wgrad_edge (reduce)");
 }

@@ -374,10 +374,11 @@ def fused_conv_ok(H: int, W_: int, Cout: int) -> bool:
 
 # ------------------------------------------------------------------------------ training: gradients
 def conv_wgrad(x: Tensor, dy: Tensor, ksize: int, upsample: bool = False, out: Optional[Tensor] = None,
-               accumulate: bool = False) -> Tensor:
+               accumulate: bool = False, dbias: Optional[Tensor] = None, bias_accumulate: bool = False) -> Tensor:
     """Weight gradient of a stride-1 conv: x NHWC (B,H,W,Cin) (or (B,H/2,W/2,Cin) with ``upsample``), dy NHWC
-    (B,H,W,Cout); returns fp32 (Cout, Cin, k, k), the layout of the master weights (model.py:116-133)."""
-    _dev(x, dy, out)
+    (B,H,W,Cout); returns fp32 (Cout, Cin, k, k), the layout of the master weights (model.py:116-133).
+    ``dbias`` (fp32 (Cout,)) also receives the bias gradient, from the same pass over dy."""
+    _dev(x, dy, out, dbias)
     B, H, W_, Cout = dy.shape
     Cin = x.shape[3]
     want = (B, H // 2, W_ // 2, Cin) if upsample else (B, H, W_, Cin)
@@ -392,8 +393,11 @@ def conv_wgrad(x: Tensor, dy: Tensor, ksize: int, upsample: bool = False, out: O
     nbytes = lib.mad_conv_wgrad_workspace(code, B, H, W_, Cin, Cout, ksize)
     ws = torch.empty((nbytes,), dtype=torch.uint8, device=x.device)
     end = TIMER.bracket("conv_wgrad", 2.0 * B * H * W_ * Cout * Cin * ksize * ksize)
-    check(lib.mad_conv_wgrad(_ptr(x), _ptr(dy), _ptr(out), _ptr(ws), nbytes, code, B, H, W_, Cin, Cout, ksize,
-                             int(upsample), int(accumulate), _stream()), "mad_conv_wgrad")
+    if dbias is not None and (tuple(dbias.shape) != (Cout,) or dbias.dtype != torch.float32 or not dbias.is_contiguous()):
+        raise ValueError("conv_wgrad: dbias must be contiguous fp32 (Cout,)")
+    check(lib.mad_conv_wgrad_bias(_ptr(x), _ptr(dy), _ptr(out), _ptr(dbias) if dbias is not None else None, _ptr(ws),
+                                  nbytes, code, B, H, W_, Cin, Cout, ksize, int(upsample), int(accumulate),
+                                  int(bias_accumulate), _stream()), "mad_conv_wgrad_bias")
     if end is not None:
         end.record()
     return out

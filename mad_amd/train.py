@@ -159,10 +159,19 @@ class UNetTrainer:
         # process group's own stream, beside the rest of the backward
         self._works.append(dist.all_reduce(self.gflat[lo:hi], group=self.group, async_op=True))
 
-    def _wgrad(self, name: str, x: Tensor, dy: Tensor, ksize: int, upsample: bool = False) -> None:
-        """Conv weight gradient written (or, when accumulating micro-batches, added) straight into the flat buffer."""
-        ops.conv_wgrad(x, dy, ksize, upsample=upsample, out=self.grads[name], accumulate=self._accumulating)
+    def _wgrad(self, name: str, x: Tensor, dy: Tensor, ksize: int, upsample: bool = False,
+               bias: Optional[str] = None, same_bias: Optional[str] = None) -> None:
+        """Conv weight gradient written (or, when accumulating micro-batches, added) straight into the flat buffer;
+        ``bias`` names the layer's bias, whose gradient comes out of the same pass over dy, and ``same_bias`` a second
+        bias that sees the same dy (a block's conv1 and its skip projection) and therefore has the same gradient."""
+        ops.conv_wgrad(x, dy, ksize, upsample=upsample, out=self.grads[name], accumulate=self._accumulating,
+                       dbias=self.grads[bias] if bias else None, bias_accumulate=self._accumulating)
+        if same_bias:
+            self.grads[same_bias].copy_(self.grads[bias])
+            self._mark(same_bias)
         self._mark(name)
+        if bias:
+            self._mark(bias)
 
     def _bgrad(self, name: str, dy: Tensor) -> None:
         ops.bias_grad(dy, out=self.grads[name], accumulate=self._accumulating)
@@ -297,15 +306,14 @@ class UNetTrainer:
         ada_v, dada_v = ada[:, e["ada_off"]:], dada[:, e["ada_off"]:]
         dy = dout
         if b.attention:
-            self._wgrad(f"{n}.proj.weight", sv.att, dout, 1)
-            self._bgrad(f"{n}.proj.bias", dout)
+            self._wgrad(f"{n}.proj.weight", sv.att, dout, 1, bias=f"{n}.proj.bias")
             datt = ops.conv2d(dout, _dgrad_weight(e, "proj.w"), None)
             dqkv = ops.attention_backward(sv.qkv, sv.att, datt, sv.lse, b.num_heads)
             # the packed qkv rows are a permutation of the reference's (model.py:359-363): undo it for the masters
             co, heads = b.out_channels, b.num_heads
             idx = torch.arange(3 * co, device=dout.device).reshape(heads, 64, 3).permute(0, 2, 1).reshape(-1)
-            gw = ops.conv_wgrad(sv.hn, dqkv, 1)
-            gb = ops.bias_grad(dqkv)
+            gb = torch.empty((3 * co,), dtype=torch.float32, device=dout.device)
+            gw = ops.conv_wgrad(sv.hn, dqkv, 1, dbias=gb)
             if self._accumulating:
                 self.grads[f"{n}.qkv.weight"].index_add_(0, idx, gw)
                 self.grads[f"{n}.qkv.bias"].index_add_(0, idx, gb)
@@ -320,8 +328,8 @@ class UNetTrainer:
             self._set(f"{n}.norm2.weight", dg)
             self._set(f"{n}.norm2.bias", db)
         # conv1 and the AdaGN in front of it
-        self._wgrad(f"{n}.conv1.weight", sv.h1, dy, 3)
-        self._bgrad(f"{n}.conv1.bias", dy)
+        self._wgrad(f"{n}.conv1.weight", sv.h1, dy, 3, bias=f"{n}.conv1.bias",
+                    same_bias=f"{n}.skip.bias" if b.skip_conv else None)
         dh1 = self._dgrad3(dy, _dgrad_weight(e, "conv1.w"))
         dh, _, dg, db = ops.gn_backward(sv.h, dh1, sv.c1, sv.h_part, e["norm1.g"], e["norm1.b"],
                                         gn_groups(b.out_channels), GN_EPS, act=True, ada=ada_v, ada_stride=ada_total,
@@ -330,8 +338,7 @@ class UNetTrainer:
         self._set(f"{n}.norm1.weight", dg)
         self._set(f"{n}.norm1.bias", db)
         # conv0 (input possibly resampled after norm0 + SiLU)
-        self._wgrad(f"{n}.conv0.weight", sv.h0, dh, 3, upsample=b.up)
-        self._bgrad(f"{n}.conv0.bias", dh)
+        self._wgrad(f"{n}.conv0.weight", sv.h0, dh, 3, upsample=b.up, bias=f"{n}.conv0.bias")
         dh0 = self._dgrad3(dh, _dgrad_weight(e, "conv0.w"))
         mode0 = ops.GRAD_FROM_DOUBLE if b.up else (ops.GRAD_FROM_HALF if b.down else ops.GRAD_SAME)
         # the residual branch's gradient w.r.t. the block input
@@ -347,7 +354,6 @@ class UNetTrainer:
                     else:
                         gsk[:, sl].copy_(g)
                 self._mark(f"{n}.skip.weight")
-            self._bgrad(f"{n}.skip.bias", dy)
             dres, res_mode = ops.conv2d(dy, _dgrad_weight(e, "skip.w"), None), ops.GRAD_SAME
         else:
             dres, res_mode = dy, mode0

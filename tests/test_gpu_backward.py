@@ -41,10 +41,10 @@ WGRAD_CASES = [
     (2, 32, 32, 32, 32, 3, True),        # nearest x2 before the conv
     (1, 24, 48, 32, 40, 3, False),       # H multiple of 8 only, Cout multiple of 8 only
     (2, 12, 12, 24, 16, 3, False),       # generic kernel: shapes the MFMA form does not tile
-    (2, 16, 32, 128, 64, 3, False),      # large-tile form, 64 co x 128 ci slices
-    (2, 32, 32, 192, 192, 3, False),     # large-tile form, ragged in one dimension, several tiles per share
-    (3, 8, 8, 256, 128, 3, False),       # large-tile form on 8x8 images, odd batch
-    (2, 32, 32, 64, 128, 3, True),       # large-tile form with the nearest x2 in the loader
+    (2, 16, 32, 128, 64, 3, False),      # Cin a multiple of 64: eight-wave form
+    (2, 32, 32, 192, 192, 3, False),     # eight-wave form, ragged second co slice, several tiles per share
+    (3, 8, 8, 256, 128, 3, False),       # eight-wave form on 8x8 images (two per tile), odd batch
+    (2, 32, 32, 64, 128, 3, True),       # eight-wave form with the nearest x2 in the loader
     (5, 64, 64, 128, 128, 3, False),     # more tiles than shares: the double-buffered loop runs many rounds
 ]
 
@@ -71,6 +71,13 @@ def test_conv_wgrad(dev, case, dt):
     assert rel_err(base.cpu() - 0.5, w0.grad) < 1e-4
     db = ops.bias_grad(_nhwc(dy, dt, dev))
     assert rel_err(db.cpu(), q(dy).double().sum((0, 2, 3))) < 2e-5
+    # weight and bias gradient from one pass over dy, fresh and accumulated
+    fb = torch.full((Cout,), 0.25, device=dev)
+    fw = ops.conv_wgrad(_nhwc(xs, dt, dev), _nhwc(dy, dt, dev), ks, upsample=up, dbias=fb)
+    assert torch.equal(fw, got)
+    assert rel_err(fb.cpu(), q(dy).double().sum((0, 2, 3))) < 2e-5
+    ops.conv_wgrad(_nhwc(xs, dt, dev), _nhwc(dy, dt, dev), ks, upsample=up, dbias=fb, bias_accumulate=True)
+    assert rel_err(fb.cpu(), 2 * q(dy).double().sum((0, 2, 3))) < 2e-5
 
 
 GN_CASES = [
