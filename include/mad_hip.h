@@ -295,6 +295,16 @@ int mad_attention_lse(const void* qkv, void* out, float* lse, int dtype, int B, 
 int mad_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* dsum,
                       void* dqkv, int dtype, int B, int L, int heads, void* stream);
 
+/* Working copies of the convolution weights of a training step, all layers in one launch: from the fp32
+ * masters (Cout,Cin,k,k) inside `master` to the forward pack (Cout,k,k,Cin) inside `fwd` and the data-gradient
+ * pack (Cin,k,k,Cout) with flipped taps inside `dgrad`, both in `dtype`.  `table` is a device array of 8 longs per
+ * layer: master offset, forward offset, gradient offset (elements), Cout, Cin, k (1 or 3), first tile, 0; a layer
+ * has ceil(Cout/32)*ceil(Cin/32) tiles and `total_tiles` is their sum.  The k <= 3 only.
+ * Replaces the per-layer `weight.to(dtype)` of Conv2d.forward (model.py:142-143) and the transposed
+ * weights autograd's conv backward builds. */
+int mad_pack_conv_weights(const float* master, void* fwd, void* dgrad, const long* table, int nconv,
+                          long total_tiles, int dtype, void* stream);
+
 /* mad_conv_wgrad for the first and last layer, whose image-side operand is NCHW fp32: each operand
  * has its own dtype (MAD_BF16 / MAD_F32) and layout flag (1 = NCHW, 0 = NHWC).  Generic vector-ALU
  * kernel.  Autograd of enc.{R}x{R}_conv and out_conv (model.py:506-508, 549-551) w.r.t. `weight`. */

@@ -114,6 +114,45 @@ __global__ __launch_bounds__(256) void adamw_kernel(AdamArgs a) {
     }
 }
 
+// Working copies of every convolution's weights from the fp32 masters, in one launch: the forward pack
+// (Cout,k,k,Cin) and the data-gradient pack (Cin,k,k,Cout) with the taps flipped.  A workgroup moves one
+// 32 co x 32 ci x k*k tile through LDS, so that the master rows (ci-major, taps minor) are read in whole
+// runs and both packs are written in 32-element runs.  `table` (device, 8 longs per conv): master offset,
+// forward-pack offset, gradient-pack offset (elements), Cout, Cin, k, first tile, unused.
+template <typename T>
+__global__ __launch_bounds__(256) void pack_conv_weights_kernel(const float* master, T* fwd, T* dgrad, const long* table,
+                                                                 int nconv) {
+    __shared__ float tile[32][9 * 32 + 1];
+    int lo = 0, hi = nconv - 1;                           // the conv whose tile range holds blockIdx.x
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (table[mid * 8 + 6] <= (long)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const long* e = table + lo * 8;
+    const int Cout = (int)e[3], Cin = (int)e[4], k = (int)e[5], kk = k * k;
+    const int t_local = (int)((long)blockIdx.x - e[6]);
+    const int ncit = (Cin + 31) / 32;
+    const int co0 = (t_local / ncit) * 32, ci0 = (t_local % ncit) * 32;
+    const int cw = Cin - ci0 < 32 ? Cin - ci0 : 32, ch = Cout - co0 < 32 ? Cout - co0 : 32;
+    const float* src = master + e[0];
+    const int run = cw * kk;                              // contiguous floats of one co row inside the tile
+    for (int i = threadIdx.x; i < ch * run; i += 256) {
+        const int co = i / run, j = i - co * run;
+        tile[co][j] = src[((size_t)(co0 + co) * Cin + ci0) * kk + j];
+    }
+    __syncthreads();
+    T* f = fwd + e[1];
+    for (int i = threadIdx.x; i < ch * kk * cw; i += 256) {
+        const int ci = i % cw, t = (i / cw) % kk, co = i / (cw * kk);
+        f[((size_t)(co0 + co) * kk + t) * Cin + ci0 + ci] = Elem<T>::store(tile[co][ci * kk + t]);
+    }
+    T* g = dgrad + e[2];
+    for (int i = threadIdx.x; i < cw * kk * ch; i += 256) {
+        const int co = i % ch, t = (i / ch) % kk, ci = i / (ch * kk);
+        g[((size_t)(ci0 + ci) * kk + (kk - 1 - t)) * Cout + co0 + co] = Elem<T>::store(tile[co][ci * kk + t]);
+    }
+}
+
 }  // namespace mad
 
 using namespace mad;
@@ -175,6 +214,20 @@ extern "C" int mad_mse_loss_grad(const float* pred, const float* target, float* 
     hipLaunchKernelGGL(mse_kernel, dim3(npartial), dim3(256), 0, (hipStream_t)stream, pred, target, grad, partial, n,
                        2.0f / (float)n);
     return check_launch("mad_mse_loss_grad");
+}
+
+extern "C" int mad_pack_conv_weights(const float* master, void* fwd, void* dgrad, const long* table, int nconv,
+                                     long total_tiles, int dtype, void* stream) {
+    MAD_REQUIRE(master && fwd && dgrad && table, "mad_pack_conv_weights: null pointer");
+    MAD_REQUIRE(dtype == MAD_BF16 || dtype == MAD_F32, "mad_pack_conv_weights: bad dtype %d", dtype);
+    MAD_REQUIRE(nconv > 0 && total_tiles > 0 && total_tiles < (1L << 31), "mad_pack_conv_weights: bad sizes");
+    if (dtype == MAD_BF16)
+        hipLaunchKernelGGL(pack_conv_weights_kernel<bf16_t>, dim3((unsigned)total_tiles), dim3(256), 0, (hipStream_t)stream,
+                           master, (bf16_t*)fwd, (bf16_t*)dgrad, table, nconv);
+    else
+        hipLaunchKernelGGL(pack_conv_weights_kernel<float>, dim3((unsigned)total_tiles), dim3(256), 0, (hipStream_t)stream,
+                           master, (float*)fwd, (float*)dgrad, table, nconv);
+    return check_launch("mad_pack_conv_weights");
 }
 
 extern "C" int mad_adamw_step(float* param, const float* grad, float* m, float* v, float* ema, size_t n, float lr,

@@ -490,6 +490,18 @@ def mse_loss_grad(pred: Tensor, target: Tensor):
     return partial.sum() / pred.numel(), grad
 
 
+def pack_conv_weights_(master: Tensor, fwd: Tensor, dgrad: Tensor, table: Tensor, total_tiles: int) -> None:
+    """Rewrite the forward and data-gradient working copies of every conv listed in ``table`` (device int64
+    (n, 8): master offset, forward offset, gradient offset, Cout, Cin, k, first tile, 0) from the flat fp32
+    masters, in one launch."""
+    _dev(master, fwd, dgrad, table)
+    if master.dtype != torch.float32 or fwd.dtype != dgrad.dtype or table.dtype != torch.int64 or table.dim() != 2 \
+            or table.shape[1] != 8:
+        raise ValueError("pack_conv_weights_: fp32 masters, packs of one dtype, int64 (n, 8) table")
+    check(lib.mad_pack_conv_weights(_ptr(master), _ptr(fwd), _ptr(dgrad), _ptr(table), table.shape[0], int(total_tiles),
+                                    _dtype_code(fwd), _stream()), "mad_pack_conv_weights")
+
+
 def adamw_step_(param: Tensor, grad: Tensor, m: Tensor, v: Tensor, ema: Optional[Tensor], lr: float, beta1: float,
                 beta2: float, eps: float, weight_decay: float, step: int, grad_scale: float = 1.0,
                 ema_decay: float = 0.0) -> None:

@@ -17,6 +17,7 @@ buffers, so the data-parallel gradient sum is a handful of large RCCL all-reduce
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -97,11 +98,16 @@ class UNetTrainer:
         self.m = torch.zeros_like(self.flat)
         self.v = torch.zeros_like(self.flat)
         self.grads: Dict[str, Tensor] = {}
+        self._offset: Dict[str, int] = {}                  # first element of a parameter in the flat buffers
+        self._param: Dict[str, Tensor] = {}
+        self._arena_of = None                              # the pack whose conv copies live in the arenas below
         off = 0
         for name, p in params:
             n = p.numel()
+            self._offset[name] = off
             self.flat[off:off + n].copy_(p.data.reshape(-1).to(torch.float32))
             p.data = self.flat[off:off + n].view(p.shape)
+            self._param[name] = p.data
             p.requires_grad_(False)
             self.grads[name] = self.gflat[off:off + n].view(p.shape)
             off += n
@@ -128,6 +134,67 @@ class UNetTrainer:
         self._launched: List[int] = []                     # bucket indices in launch order (last backward)
         self._overlap = False
         self._reduce_fn = None                             # test hook: called instead of dist.all_reduce
+
+    # ------------------------------------------------------------------ working copies of the weights
+    REPACK = os.environ.get("MAD_TRAIN_REPACK", "1") != "0"
+
+    def _adopt_pack(self, P: dict) -> None:
+        """Move the conv working copies of a freshly built pack into two arenas (forward layout; transposed with
+        flipped taps for the data gradient) that one kernel rewrites from the masters after every update."""
+        dev, dt = self.flat.device, P["dtype"]
+        rows, targets, off, tiles = [], [], 0, 0
+        for e in P["blocks"]:
+            n = e["spec"].name
+            for key in ("conv0.w", "conv1.w", "skip.w", "proj.w"):
+                if key not in e:
+                    continue
+                Cout, k, _, Cin = e[key].shape
+                rows.append([self._offset[f"{n}.{key[:-1]}weight"], off, off, Cout, Cin, k, tiles, 0])
+                targets.append((e, key, Cout, Cin, k, off))
+                off += -(-Cout * Cin * k * k // 128) * 128
+                tiles += -(-Cout // 32) * -(-Cin // 32)
+        self._arena_f = torch.empty(off, dtype=dt, device=dev)
+        self._arena_t = torch.empty(off, dtype=dt, device=dev)
+        for e, key, Cout, Cin, k, o in targets:
+            n = Cout * Cin * k * k
+            e[key] = self._arena_f[o:o + n].view(Cout, k, k, Cin)
+            e[key + ".T"] = self._arena_t[o:o + n].view(Cin, k, k, Cout)
+            if key == "skip.w":
+                e["skip.w2d"] = e[key].reshape(Cout, -1)
+        self._pack_table = torch.tensor(rows, dtype=torch.int64, device=dev)
+        self._pack_tiles = tiles
+        self._arena_of = P
+        ops.pack_conv_weights_(self.flat, self._arena_f, self._arena_t, self._pack_table, tiles)
+
+    def _refresh_pack(self) -> None:
+        """After an update: rewrite the working copies in place (model.py's pack stays valid: biases, norm and
+        embedding weights alias the masters; the conv copies come from one kernel; the few regrouped tensors
+        are recomputed here as `DhariwalUNet._pack` computes them)."""
+        P = self.unet._packed
+        if not self.REPACK or P is None or self._arena_of is not P:
+            self.unet.invalidate()
+            self._arena_of = None
+            return
+        ops.pack_conv_weights_(self.flat, self._arena_f, self._arena_t, self._pack_table, self._pack_tiles)
+        W, s = self._param, self.unet.spec
+        for e in P["blocks"]:
+            b = e["spec"]
+            n = b.name
+            if b.skip_conv:
+                torch.add(e["conv1.b"], e["skip.b"], out=e["conv1+skip.b"])
+            if b.attention:
+                co, heads = b.out_channels, b.num_heads
+                if "qkv.idx" not in e:
+                    e["qkv.idx"] = torch.arange(3 * co, device=self.flat.device).reshape(heads, 64, 3).permute(0, 2, 1).reshape(-1)
+                e["qkv.w"].copy_(W[f"{n}.qkv.weight"].permute(0, 2, 3, 1)[e["qkv.idx"]])
+                e["qkv.b"].copy_(W[f"{n}.qkv.bias"][e["qkv.idx"]])
+                e.pop("qkv.w.T", None)
+        torch.cat([W[f"{b.name}.affine.weight"] for b in s.blocks()], 0, out=P["aff.w"])
+        torch.cat([W[f"{b.name}.affine.bias"] for b in s.blocks()], 0, out=P["aff.b"])
+        P["out.w"].copy_(W["out_conv.weight"].permute(0, 2, 3, 1))
+        P["out.w32"][:s.out_channels].copy_(P["out.w"])
+        self.unet._pack_version += 1
+        P["version"] = self.unet._pack_version
 
     # ------------------------------------------------------------------ helpers
     def _set(self, name: str, g: Tensor) -> None:
@@ -249,6 +316,8 @@ class UNetTrainer:
         """Train-mode ``DhariwalUNet.forward`` (model.py:553-590); returns (pred NCHW fp32, tape)."""
         u, s = self.unet, self.unet.spec
         P = u._pack(x.device)
+        if self.REPACK and self._arena_of is not P:
+            self._adopt_pack(P)
         dt = P["dtype"]
         B = x.shape[0]
         x = x.to(torch.float32).contiguous()
@@ -500,7 +569,7 @@ class UNetTrainer:
                         self.betas[1], self.eps, self.weight_decay, self.step_count, grad_scale=scale,
                         ema_decay=self.ema_decay())
         self.micro_batches = 0
-        self.unet.invalidate()
+        self._refresh_pack()
 
     def train_step(self, x0: Tensor, class_labels: Optional[Tensor], alphas_cumprod: Tensor,
                    generator: Optional[torch.Generator] = None, num_timesteps: int = 1000, accumulation: int = 1,

@@ -144,6 +144,41 @@ def test_training_reduces_loss(dev):
     assert float((tr.ema - tr.flat).abs().max()) > 0
 
 
+@pytest.mark.parametrize("cfg_file,precision", [("model_tiny.yaml", "fp32"), ("model_tiny.yaml", "bf16"),
+                                                ("model_64_64.yaml", "bf16")])
+def test_refreshed_working_copies_equal_a_fresh_pack(dev, cfg_file, precision):
+    """After an update the working copies of the weights are rewritten in place (one kernel for the convs'
+    forward and data-gradient layouts, a few torch ops for the regrouped tensors): every entry must equal
+    what packing the updated masters from scratch gives."""
+    from mad_amd.train import UNetTrainer, _dgrad_weight
+    cfg, m, sd, x, t, lab, target = _setup(cfg_file, precision, dev, B=2)
+    tr = UNetTrainer(m.unet, lr=1e-2, dropout=0.0)
+    assert tr.REPACK
+    for _ in range(2):
+        tr.forward_backward(x[:2].to(dev), t[:2].to(dev), lab[:2].to(dev), target[:2].to(dev))
+        tr.step()
+    P = m.unet._packed
+    assert P is not None and tr._arena_of is P
+    got_blocks = [{k: v.clone() for k, v in e.items() if torch.is_tensor(v)} for e in P["blocks"]]
+    got_top = {k: v.clone() for k, v in P.items() if torch.is_tensor(v)}
+    m.unet.invalidate()
+    fresh = m.unet._pack(dev)
+    assert fresh is not P
+    for k, v in fresh.items():
+        if torch.is_tensor(v):
+            assert torch.equal(got_top[k], v), k
+    n_t = 0
+    for e_got, e in zip(got_blocks, fresh["blocks"]):
+        for k, v in e.items():
+            if torch.is_tensor(v):
+                assert torch.equal(e_got[k], v), (e["spec"].name, k)
+        for k in ("conv0.w", "conv1.w", "skip.w", "proj.w"):
+            if k in e:
+                assert torch.equal(e_got[k + ".T"], _dgrad_weight(dict(e), k)), (e["spec"].name, k + ".T")
+                n_t += 1
+    assert n_t >= 2 * len(got_blocks)
+
+
 def test_data_parallel_and_accumulated_steps_equal_the_big_batch(dev):
     """What the all-reduce computes, done by hand (the collective itself is covered on gloo): two replicas on
     half batches, gradients summed, update scaled by 1/world -- and the same through gradient accumulation --
