@@ -277,6 +277,9 @@ int mad_gn_bwd_finalize(const float* stat1, int C1, int nsplit1, const float* st
                         const float* gsum, int nsplit_g, const float* gamma, const float* beta,
                         const float* ada, int ada_stride, float* bcoef, float* dgb, float* dada, int B,
                         int groups, int HW, float eps, void* stream);
+/* dgamma[c], dbeta[c] (+)= sum_b dgb[b][c], dgb[b][C + c]: the batch sum of finalize's per-image rows, written
+ * straight to their (separate) destinations. */
+int mad_gn_affine_grad(const float* dgb, int B, int C, float* dgamma, float* dbeta, int accumulate, void* stream);
 int mad_gn_bwd_apply(const void* x1, int C1, const void* x2, int C2, const void* dy, int dy_mode,
                      const float* coef, int act, unsigned long long drop_seed, float drop_p,
                      const float* bcoef, const void* add1, int add1_mode,

@@ -69,6 +69,7 @@ SIGNATURES = {
     "mad_gn_bwd_apply": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, ctypes.c_ulonglong,
                                  c_float, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p] + [c_int] * 4 +
                          [c_void_p]),
+    "mad_gn_affine_grad": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
     "mad_pack_conv_weights": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, ctypes.c_long, c_int, c_void_p]),
     "mad_conv_wgrad_edge_workspace": (ctypes.c_size_t, [c_int] * 6),
     "mad_conv_wgrad_edge": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, ctypes.c_size_t] +

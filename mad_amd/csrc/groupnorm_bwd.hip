@@ -255,6 +255,18 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(GnBwdApplyArgs a) {
     }
 }
 
+// dgamma[c], dbeta[c] (+)= sum over the batch of the per-image rows finalize wrote (dgb (B, 2C): dgamma then
+// dbeta), in batch order; the two halves go to separate destinations (the flat gradient buffer).
+__global__ __launch_bounds__(256) void gn_affine_grad_kernel(const float* dgb, int B, int C, float* dgamma, float* dbeta,
+                                                              int accumulate) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= 2 * C) return;
+    float s = 0.0f;
+    for (int b = 0; b < B; ++b) s += dgb[(size_t)b * 2 * C + c];
+    float* d = c < C ? dgamma + c : dbeta + (c - C);
+    *d = accumulate ? *d + s : s;
+}
+
 }  // namespace mad
 
 using namespace mad;
@@ -310,6 +322,15 @@ extern "C" int mad_gn_bwd_finalize(const float* stat1, int C1, int nsplit1, cons
     a.nsg = nsplit_g; a.ada_stride = ada_stride; a.groups = groups; a.HW = HW; a.eps = eps;
     hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(groups, B), dim3(64), 0, (hipStream_t)stream, a);
     return check_launch("mad_gn_bwd_finalize");
+}
+
+extern "C" int mad_gn_affine_grad(const float* dgb, int B, int C, float* dgamma, float* dbeta, int accumulate,
+                                  void* stream) {
+    MAD_REQUIRE(dgb && dgamma && dbeta, "mad_gn_affine_grad: null pointer");
+    MAD_REQUIRE(B > 0 && C > 0, "mad_gn_affine_grad: bad shape");
+    hipLaunchKernelGGL(gn_affine_grad_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, (hipStream_t)stream, dgb, B, C,
+                       dgamma, dbeta, accumulate);
+    return check_launch("mad_gn_affine_grad");
 }
 
 extern "C" int mad_gn_bwd_apply(const void* x1, int C1, const void* x2, int C2, const void* dy, int dy_mode,

@@ -523,15 +523,17 @@ def gn_backward(x1: Tensor, dy: Tensor, coef: Tensor, stat1: Tensor, gamma: Tens
                 ada: Optional[Tensor] = None, ada_stride: int = 0, dada: Optional[Tensor] = None,
                 dy_mode: int = GRAD_SAME, add1: Optional[Tensor] = None, add1_mode: int = GRAD_SAME,
                 add2: Optional[Tensor] = None, add2_mode: int = GRAD_SAME, need_dx: bool = True,
-                drop_seed: int = 0, drop_p: float = 0.0):
+                drop_seed: int = 0, drop_p: float = 0.0, dgamma: Optional[Tensor] = None,
+                dbeta: Optional[Tensor] = None, accumulate: bool = False):
     """Backward of h = act(GroupNorm([x1, x2]) * (1 + scale) + shift).
 
     ``coef`` and ``stat1``/``stat2`` are the forward's (a, d) table and statistics partials; ``dy`` is the
     gradient w.r.t. h (all channels, resolution per ``dy_mode``); with ``drop_p`` > 0, h had been dropped out by
     ``gn_apply(..., drop_seed, drop_p)`` and dy is masked the same way first.  Returns (dx1, dx2, dgamma, dbeta); the
     AdaGN gradients are written into ``dada`` (a view laid out like ``ada``).  ``add1``/``add2`` are further
-    gradients reaching x, added into dx."""
-    _dev(x1, x2, dy, coef, stat1, stat2, gamma, beta, add1, add2)
+    gradients reaching x, added into dx.  ``dgamma``/``dbeta`` (fp32 (C,)) receive the affine gradients in place
+    (added when ``accumulate``)."""
+    _dev(x1, x2, dy, coef, stat1, stat2, gamma, beta, add1, add2, dgamma, dbeta)
     B, H, W_, C1 = x1.shape
     C2 = 0 if x2 is None else x2.shape[3]
     C = C1 + C2
@@ -548,7 +550,14 @@ def gn_backward(x1: Tensor, dy: Tensor, coef: Tensor, stat1: Tensor, gamma: Tens
                                   None if ada is None else ada.data_ptr(), ada_stride, _ptr(bcoef), _ptr(dgb),
                                   None if dada is None else dada.data_ptr(), B, groups, H * W_, float(eps), _stream()),
           "mad_gn_bwd_finalize")
-    dg = bias_grad(dgb)
+    if dgamma is None or dbeta is None:
+        dgamma = torch.empty((C,), dtype=torch.float32, device=x1.device)
+        dbeta = torch.empty((C,), dtype=torch.float32, device=x1.device)
+        accumulate = False
+    elif dgamma.numel() != C or dbeta.numel() != C or dgamma.dtype != torch.float32 or dbeta.dtype != torch.float32:
+        raise ValueError("gn_backward: dgamma / dbeta must be fp32 with C elements")
+    check(lib.mad_gn_affine_grad(_ptr(dgb), B, C, _ptr(dgamma), _ptr(dbeta), int(accumulate), _stream()),
+          "mad_gn_affine_grad")
     dx1 = dx2 = None
     if need_dx:
         dx1 = torch.empty_like(x1)
@@ -556,7 +565,7 @@ def gn_backward(x1: Tensor, dy: Tensor, coef: Tensor, stat1: Tensor, gamma: Tens
         check(lib.mad_gn_bwd_apply(_ptr(x1), C1, _ptr(x2), C2, _ptr(dy), dy_mode, _ptr(coef), int(act), drop_seed, float(drop_p),
                                    _ptr(bcoef), _ptr(add1), add1_mode, _ptr(add2), add2_mode, _ptr(dx1), _ptr(dx2), code, B, H, W_,
                                    _stream()), "mad_gn_bwd_apply")
-    return dx1, dx2, dg[:C], dg[C:]
+    return dx1, dx2, dgamma, dbeta
 
 
 # ------------------------------------------------------------------------------ GroupNorm

@@ -393,9 +393,11 @@ class UNetTrainer:
             self._mark(f"{n}.qkv.bias")
             dhn = ops.conv2d(dqkv, _dgrad_weight(e, "qkv.w"), None)
             dy, _, dg, db = ops.gn_backward(sv.y, dhn, sv.c2, sv.y_part, e["norm2.g"], e["norm2.b"],
-                                            gn_groups(b.out_channels), GN_EPS, act=False, add1=dout)
-            self._set(f"{n}.norm2.weight", dg)
-            self._set(f"{n}.norm2.bias", db)
+                                            gn_groups(b.out_channels), GN_EPS, act=False, add1=dout,
+                                            dgamma=self.grads[f"{n}.norm2.weight"], dbeta=self.grads[f"{n}.norm2.bias"],
+                                            accumulate=self._accumulating)
+            self._mark(f"{n}.norm2.weight")
+            self._mark(f"{n}.norm2.bias")
         # conv1 and the AdaGN in front of it
         self._wgrad(f"{n}.conv1.weight", sv.h1, dy, 3, bias=f"{n}.conv1.bias",
                     same_bias=f"{n}.skip.bias" if b.skip_conv else None)
@@ -403,9 +405,11 @@ class UNetTrainer:
         dh, _, dg, db = ops.gn_backward(sv.h, dh1, sv.c1, sv.h_part, e["norm1.g"], e["norm1.b"],
                                         gn_groups(b.out_channels), GN_EPS, act=True, ada=ada_v, ada_stride=ada_total,
                                         dada=dada_v, drop_seed=sv.seed or 0,
-                                        drop_p=self.dropout if sv.seed is not None else 0.0)
-        self._set(f"{n}.norm1.weight", dg)
-        self._set(f"{n}.norm1.bias", db)
+                                        drop_p=self.dropout if sv.seed is not None else 0.0,
+                                        dgamma=self.grads[f"{n}.norm1.weight"], dbeta=self.grads[f"{n}.norm1.bias"],
+                                        accumulate=self._accumulating)
+        self._mark(f"{n}.norm1.weight")
+        self._mark(f"{n}.norm1.bias")
         # conv0 (input possibly resampled after norm0 + SiLU)
         self._wgrad(f"{n}.conv0.weight", sv.h0, dh, 3, upsample=b.up, bias=f"{n}.conv0.bias")
         dh0 = self._dgrad3(dh, _dgrad_weight(e, "conv0.w"))
@@ -436,9 +440,11 @@ class UNetTrainer:
         dx, dskip, dg, db = ops.gn_backward(sv.x, dh0, sv.c0, sv.x_part, e["norm0.g"], e["norm0.b"],
                                             gn_groups(b.in_channels), GN_EPS, act=True, x2=sv.skip,
                                             stat2=sv.skip_part, dy_mode=mode0, add1=dres, add1_mode=res_mode,
-                                            add2=add2)
-        self._set(f"{n}.norm0.weight", dg)
-        self._set(f"{n}.norm0.bias", db)
+                                            add2=add2,
+                                        dgamma=self.grads[f"{n}.norm0.weight"], dbeta=self.grads[f"{n}.norm0.bias"],
+                                        accumulate=self._accumulating)
+        self._mark(f"{n}.norm0.weight")
+        self._mark(f"{n}.norm0.bias")
         return dx, dskip
 
     def backward(self, tape: dict, dpred: Tensor) -> None:
@@ -465,9 +471,11 @@ class UNetTrainer:
         wT[..., :Co] = P["out.w"].flip(1, 2).permute(3, 1, 2, 0).to(dt)
         dhact = self._dgrad3(dp, wT)
         dh, _, dg, db = ops.gn_backward(tape["h_last"], dhact, tape["c_out"], tape["h_last_part"], P["out_norm.g"],
-                                        P["out_norm.b"], gn_groups(Cf), GN_EPS, act=True)
-        self._set("out_norm.weight", dg)
-        self._set("out_norm.bias", db)
+                                        P["out_norm.b"], gn_groups(Cf), GN_EPS, act=True,
+                                        dgamma=self.grads["out_norm.weight"], dbeta=self.grads["out_norm.bias"],
+                                        accumulate=self._accumulating)
+        self._mark("out_norm.weight")
+        self._mark("out_norm.bias")
 
         dada = torch.zeros_like(tape["ada"])
         saved: List[_Saved] = tape["saved"]
