@@ -240,10 +240,6 @@ class UNetTrainer:
         if bias:
             self._mark(bias)
 
-    def _bgrad(self, name: str, dy: Tensor) -> None:
-        ops.bias_grad(dy, out=self.grads[name], accumulate=self._accumulating)
-        self._mark(name)
-
     @staticmethod
     def _conv3(x: Tensor, w: Tensor, b: Optional[Tensor], upsample: bool = False, residual: Optional[Tensor] = None,
                res_mode: int = _lib.RES_NONE, want_stats: bool = True):
