@@ -137,6 +137,7 @@ class UNetTrainer:
 
     # ------------------------------------------------------------------ working copies of the weights
     REPACK = os.environ.get("MAD_TRAIN_REPACK", "1") != "0"
+    FUSE_SKIP = os.environ.get("MAD_TRAIN_FUSE_SKIP", "1") != "0"
 
     def _adopt_pack(self, P: dict) -> None:
         """Move the conv working copies of a freshly built pack into two arenas (forward layout; transposed with
@@ -287,7 +288,15 @@ class UNetTrainer:
             self._drop_calls += 1
             sv.seed = (self.seed << 32) ^ (self.step_count << 12) ^ self._drop_calls
         sv.h1 = ops.gn_apply(sv.h, sv.c1, act=True, drop_seed=sv.seed or 0, drop_p=self.dropout if sv.seed is not None else 0.0)
-        if b.skip_conv:
+        cm = 32 if x.dtype == torch.bfloat16 else 16
+        if (b.skip_conv and self.FUSE_SKIP and ops.fused_conv_ok(b.res_out, b.res_out, b.out_channels)
+                and b.out_channels % cm == 0 and x.shape[3] % cm == 0 and (skip is None or skip.shape[3] % cm == 0)):
+            # the 1x1 projection of the block input rides in conv1's launch (more reduction steps of the same
+            # accumulators) instead of a pass of its own that writes a residual tensor conv1 then re-reads
+            sv.y, sv.y_part = ops.conv3x3_fused(sv.h1, e["conv1.w"], e["conv1+skip.b"], coef=None, want_stats=True,
+                                                skip=(x, skip, e["skip.w2d"]))
+            res = mode = None
+        elif b.skip_conv:
             res, mode = ops.conv2d(x, e["skip.w"], e["skip.b"], x2=skip), _lib.RES_SAME
         elif b.up:
             res, mode = x, _lib.RES_UP
@@ -295,7 +304,8 @@ class UNetTrainer:
             res, mode = x, _lib.RES_DOWN
         else:
             res, mode = x, _lib.RES_SAME
-        sv.y, sv.y_part = self._conv3(sv.h1, e["conv1.w"], e["conv1.b"], residual=res, res_mode=mode)
+        if mode is not None:
+            sv.y, sv.y_part = self._conv3(sv.h1, e["conv1.w"], e["conv1.b"], residual=res, res_mode=mode)
         out, out_part = sv.y, sv.y_part
         if b.attention:
             sv.y_part = self._part(sv.y, sv.y_part)
