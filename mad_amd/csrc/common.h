@@ -72,24 +72,38 @@ __device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_r
 
 // Dropout keep-mask from a counter hash: element e of the tensor dropped with `seed` is kept with probability
 // 1-p and scaled by 1/(1-p).  The same (seed, e) gives the same decision in the forward and in the backward.
+// Decisions are drawn for groups of 8 consecutive elements: a two-round hash of the group index gives the
+// first pair (16 bits each against a 16-bit threshold), one more round each further pair -- 5 rounds per 8
+// elements, since the integer multiplies of a round cost more than the activation they sit beside.
 __host__ __device__ __forceinline__ unsigned mix32(unsigned x) {
     x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
     return x;
 }
 struct DropMask {
-    unsigned s0, s1, thr;      // thr == 0: no dropout
+    unsigned s0, s1, thr;      // thr (of 65536) == 0: no dropout
     float scale;
 };
 inline DropMask make_drop_mask(unsigned long long seed, float p) {
     DropMask m;
     m.s0 = mix32((unsigned)seed); m.s1 = mix32((unsigned)(seed >> 32) ^ 0x9e3779b9u);
-    m.thr = p > 0.0f ? (unsigned)((double)p * 4294967296.0) : 0u;
-    m.scale = p > 0.0f ? 1.0f / (1.0f - p) : 1.0f;
+    m.thr = p > 0.0f ? (unsigned)((double)p * 65536.0 + 0.5) : 0u;
+    m.scale = m.thr ? 65536.0f / (float)(65536u - m.thr) : 1.0f;
     return m;
 }
-__device__ __forceinline__ float drop_factor(const DropMask& m, unsigned long long e) {
-    const unsigned h = mix32(mix32((unsigned)e ^ m.s0) + (unsigned)(e >> 32) + m.s1);
-    return h >= m.thr ? m.scale : 0.0f;
+// keep factors of the N (4 or 8) elements e0 .. e0+N-1, e0 a multiple of N
+template <int N> __device__ __forceinline__ void drop_factors(const DropMask& m, unsigned long long e0, float (&f)[N]) {
+    static_assert(N == 4 || N == 8, "whole or half groups");
+    const unsigned long long grp = e0 >> 3;
+    const unsigned h0 = mix32(mix32((unsigned)grp ^ m.s0) + (unsigned)(grp >> 32) + m.s1);
+    const unsigned first = N == 8 ? 0u : ((unsigned)e0 & 4u) >> 1;       // pair index of e0 inside its group
+#pragma unroll
+    for (int i = 0; i < N; i += 2) {
+        const unsigned w = first + (i >> 1);
+        const unsigned hw = mix32(h0 + w * 0x9e3779b9u);
+        const unsigned h = w == 0 ? h0 : hw;
+        f[i] = (h & 0xffffu) >= m.thr ? m.scale : 0.0f;
+        f[i + 1] = (h >> 16) >= m.thr ? m.scale : 0.0f;
+    }
 }
 
 }  // namespace mad

@@ -179,8 +179,10 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x1,
             }
             if (dm.thr) {                                   // dropout of the output element (its linear index in y)
                 const unsigned long long e0 = ((unsigned long long)b * HWo + p) * C + c;
+                float keep[VEC];
+                drop_factors<VEC>(dm, e0, keep);
 #pragma unroll
-                for (int i = 0; i < VEC; ++i) r[i] *= drop_factor(dm, e0 + i);
+                for (int i = 0; i < VEC; ++i) r[i] *= keep[i];
             }
             Vec16<T> o;
             o.pack(r);

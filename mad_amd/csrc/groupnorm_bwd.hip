@@ -91,8 +91,10 @@ __global__ __launch_bounds__(256) void gn_bwd_partial_kernel(GnBwdArgs a, float*
                 load_grad<T>((const T*)a.dy, a.dy_mode, b, p / a.W, p % a.W, a.H, a.W, C, c, g);
                 if (a.dm.thr) {
                     const unsigned long long e0 = ((unsigned long long)b * HW + p) * C + c;
+                    float keep[VEC];
+                    drop_factors<VEC>(a.dm, e0, keep);
 #pragma unroll
-                    for (int i = 0; i < VEC; ++i) g[i] *= drop_factor(a.dm, e0 + i);
+                    for (int i = 0; i < VEC; ++i) g[i] *= keep[i];
                 }
 #pragma unroll
                 for (int i = 0; i < VEC; ++i) {
@@ -230,8 +232,10 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(GnBwdApplyArgs a) {
             load_grad<T>((const T*)s.dy, s.dy_mode, b, y, x, s.H, s.W, C, c, g);
             if (s.dm.thr) {
                 const unsigned long long e0 = (unsigned long long)pix * C + c;
+                float keep[VEC];
+                drop_factors<VEC>(s.dm, e0, keep);
 #pragma unroll
-                for (int i = 0; i < VEC; ++i) g[i] *= drop_factor(s.dm, e0 + i);
+                for (int i = 0; i < VEC; ++i) g[i] *= keep[i];
             }
 #pragma unroll
             for (int i = 0; i < VEC; ++i) {

@@ -61,8 +61,10 @@ __global__ __launch_bounds__(256) void dropout_kernel(const T* __restrict__ x, T
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (size_t)gridDim.x * 256) {
         Vec16<T> v; v.load(x + i * VEC);
         float f[VEC]; v.unpack(f);
+        float keep[VEC];
+        drop_factors<VEC>(m, i * VEC, keep);
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) f[j] *= drop_factor(m, i * VEC + j);
+        for (int j = 0; j < VEC; ++j) f[j] *= keep[j];
         v.pack(f);
         v.store(y + i * VEC);
     }

@@ -193,7 +193,7 @@ def test_fused_dropout_forward_and_backward(dev, dt):
         assert rel_err(fused.float().cpu(), two_pass.float().cpu()) < 8e-3
     mask = ops.dropout_(torch.ones_like(plain, dtype=torch.float32), seed, p)          # 0 or 1/(1-p), NHWC
     frac = float((mask == 0).float().mean())
-    assert 0.08 < frac < 0.12 and abs(float(mask.max()) - 1 / (1 - p)) < 1e-6
+    assert 0.08 < frac < 0.12 and abs(float(mask.max()) - 1 / (1 - p)) < 2e-5      # p is quantised to 1/65536
     xr = x.double().requires_grad_(True)
     gr, br = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
     hh = F.silu(F.group_norm(xr, groups, gr, br, eps=1e-5)) * mask.permute(0, 3, 1, 2).cpu().double()
