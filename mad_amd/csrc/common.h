@@ -70,6 +70,17 @@ template <typename T> struct Vec16 {
 // x * sigmoid(x); v_exp_f32 and v_rcp_f32 (1 ulp each)
 __device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 
+// Raise a kernel's dynamic-LDS limit.  The attribute belongs to the current device's copy of the kernel, so
+// it is set again whenever the calling thread has moved to another device (`done_for` holds the last one).
+inline bool raise_lds_limit(const void* kernel, int bytes, int* done_for) {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    if (*done_for == dev) return true;
+    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return false;
+    *done_for = dev;
+    return true;
+}
+
 // Dropout keep-mask from a counter hash: element e of the tensor dropped with `seed` is kept with probability
 // 1-p and scaled by 1/(1-p).  The same (seed, e) gives the same decision in the forward and in the backward.
 // Decisions are drawn for groups of 8 consecutive elements: a two-round hash of the group index gives the

@@ -463,13 +463,9 @@ __global__ __launch_bounds__(256) void conv_out_kernel(const T* __restrict__ x, 
 
 template <typename T, int BM, int BN, int NST> static int launch_igemm(ConvArgs a, hipStream_t s) {
     constexpr int lds = conv_lds_bytes<BM, BN, NST>();
-    static bool attr_set = false;
-    if (!attr_set) {
-        MAD_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<T, BM, BN, NST>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess,
-                    "mad_conv2d: cannot raise the dynamic LDS limit to %d", lds);
-        attr_set = true;
-    }
+    static int lds_dev = -1;
+    MAD_REQUIRE(raise_lds_limit(reinterpret_cast<const void*>(&conv_igemm_kernel<T, BM, BN, NST>), lds, &lds_dev),
+                "mad_conv2d: cannot raise the dynamic LDS limit to %d", lds);
     a.mtiles = (a.M + BM - 1) / BM;
     a.ntiles = a.Cout / BN;
     hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, NST>), dim3(a.mtiles * a.ntiles), dim3(256), lds, s, a);

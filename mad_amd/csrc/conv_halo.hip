@@ -528,12 +528,10 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / 2) void conv3x3_halo_kernel
 template <typename T, bool FUSE, int WM, int WN, int TN, bool OUT_NCHW, bool SKIP = false>
 static int launch_halo(const HaloArgs& a, hipStream_t s, const char* what) {
     constexpr int lds = halo_lds_bytes<WN * TN * 32>();
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<T, FUSE, WM, WN, TN, OUT_NCHW, SKIP>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_set = true;
-    }
+    static int lds_dev = -1;
+    MAD_REQUIRE(raise_lds_limit(reinterpret_cast<const void*>(&conv3x3_halo_kernel<T, FUSE, WM, WN, TN, OUT_NCHW, SKIP>),
+                                lds, &lds_dev),
+                "%s: cannot raise the dynamic LDS limit to %d", what, lds);
     const int grid = a.B * a.tiles_x * a.tiles_y * a.ntiles_n;
     hipLaunchKernelGGL((conv3x3_halo_kernel<T, FUSE, WM, WN, TN, OUT_NCHW, SKIP>), dim3(grid), dim3(64 * WM * WN), lds, s, a);
     return check_launch(what);

@@ -503,16 +503,11 @@ int mad_halo2_try(const void* x1, int C1, const void* x2, int C2, const float* c
     a.tiles_x = W / HT; a.tiles_y = H / HT; a.ntiles_n = Cout / BN; a.ntiles_total = ntiles_total;
     a.skew = 0;
     if (const char* f = getenv("MAD_HALO_V2_SKEW")) a.skew = atoi(f);          // tuning aid
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)conv3x3_halo2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                LDS_BYTES) != hipSuccess ||
-            hipFuncSetAttribute((const void*)conv3x3_halo2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                LDS_BYTES) != hipSuccess) {
-            set_error("mad_conv3x3_fused: cannot raise the dynamic LDS limit to %d", LDS_BYTES);
-            return 1;
-        }
-        attr_set = true;
+    static int lds_dev[2] = {-1, -1};
+    if (!raise_lds_limit((const void*)conv3x3_halo2_kernel<true>, LDS_BYTES, &lds_dev[0]) ||
+        !raise_lds_limit((const void*)conv3x3_halo2_kernel<false>, LDS_BYTES, &lds_dev[1])) {
+        set_error("mad_conv3x3_fused: cannot raise the dynamic LDS limit to %d", LDS_BYTES);
+        return 1;
     }
     const int grid = 256;                              // one persistent workgroup per CU
     if (coef)

@@ -284,13 +284,9 @@ __global__ __launch_bounds__(512) void conv3x3_img8_kernel(Img8Args a) {
 }
 
 template <typename T, bool FUSE> static int launch_img8(const Img8Args& a, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        MAD_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_img8_kernel<T, FUSE>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, i8::LDS_BYTES) == hipSuccess,
-                    "mad_conv3x3_img8: cannot raise the dynamic LDS limit to %d", i8::LDS_BYTES);
-        attr_set = true;
-    }
+    static int lds_dev = -1;
+    MAD_REQUIRE(raise_lds_limit(reinterpret_cast<const void*>(&conv3x3_img8_kernel<T, FUSE>), i8::LDS_BYTES, &lds_dev),
+                "mad_conv3x3_img8: cannot raise the dynamic LDS limit to %d", i8::LDS_BYTES);
     hipLaunchKernelGGL((conv3x3_img8_kernel<T, FUSE>), dim3(a.B * (a.Cout / i8::BN)), dim3(i8::NTHREADS), i8::LDS_BYTES, s, a);
     return check_launch("mad_conv3x3_img8");
 }

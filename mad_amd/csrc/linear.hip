@@ -128,13 +128,9 @@ extern "C" int mad_linear_f32(const float* x, const float* W, const float* bias,
     const int grid = std::max(1, std::min((groups + 15) / 16, 512));   // ~4 feature groups per wave
     if ((size_t)32 * K * sizeof(float) <= 128 * 1024) {
         const size_t lds = (size_t)32 * K * sizeof(float);
-        static bool attr_set = false;
-        if (!attr_set) {
-            MAD_REQUIRE(hipFuncSetAttribute((const void*)linear_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                            128 * 1024) == hipSuccess,
-                        "mad_linear_f32: cannot raise the dynamic LDS limit");
-            attr_set = true;
-        }
+        static int lds_dev = -1;
+        MAD_REQUIRE(raise_lds_limit((const void*)linear_kernel<32>, 128 * 1024, &lds_dev),
+                    "mad_linear_f32: cannot raise the dynamic LDS limit");
         hipLaunchKernelGGL(linear_kernel<32>, dim3(grid), dim3(256), lds, (hipStream_t)stream, x, W, bias, y, rows, K,
                            N, act_in, act_out, accumulate);
     } else {

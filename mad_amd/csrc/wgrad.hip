@@ -453,14 +453,10 @@ extern "C" int mad_conv_wgrad_bias(const void* x, const void* dy, float* dw, flo
 #define MAD_WG_LAUNCH2(KS, SW, BIAS)                                                                                 \
     do {                                                                                                             \
         if (wci == 2) {                                                                                              \
-            static bool big_lds = false;                                                                             \
-            if (!big_lds) {                                                                                          \
-                MAD_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_mfma_kernel<KS, SW, 2, BIAS>),  \
-                                                hipFuncAttributeMaxDynamicSharedMemorySize,                          \
-                                                wg::lds_bytes(2)) == hipSuccess,                                     \
-                            "mad_conv_wgrad: cannot raise the dynamic LDS limit");                                   \
-                big_lds = true;                                                                                      \
-            }                                                                                                        \
+            static int lds_dev = -1;                                                                                 \
+            MAD_REQUIRE(raise_lds_limit(reinterpret_cast<const void*>(&wgrad_mfma_kernel<KS, SW, 2, BIAS>),          \
+                                        wg::lds_bytes(2), &lds_dev),                                                 \
+                        "mad_conv_wgrad: cannot raise the dynamic LDS limit");                                       \
             hipLaunchKernelGGL((wgrad_mfma_kernel<KS, SW, 2, BIAS>), grid, dim3(512), wg::lds_bytes(2), s, a);       \
         } else {                                                                                                     \
             hipLaunchKernelGGL((wgrad_mfma_kernel<KS, SW, 1, BIAS>), grid, dim3(256), wg::lds_bytes(1), s, a);       \
