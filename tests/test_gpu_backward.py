@@ -202,3 +202,35 @@ def test_fused_dropout_forward_and_backward(dev, dt):
                                     drop_seed=seed, drop_p=p)
     assert rel_err(dx.float().permute(0, 3, 1, 2).cpu(), xr.grad) < (2e-5 if dt == torch.float32 else 8e-3)
     assert rel_err(dg.cpu(), gr.grad) < 1e-4 and rel_err(db.cpu(), br.grad) < 1e-4
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
+def test_pack_conv_weights_ragged_layers(dev, dt):
+    """One launch repacks several layers: shapes that are not multiples of the 32 x 32 tile, 1x1 and 3x3, at
+    arbitrary offsets of the flat master buffer, against flip / permute in torch."""
+    from mad_amd import ops
+    layers = [(40, 24, 3), (64, 96, 1), (33, 65, 3), (128, 32, 3), (8, 8, 1)]      # Cout, Cin, k
+    g = torch.Generator().manual_seed(9)
+    pad = 7                                                                        # masters need not be aligned
+    total = sum(co * ci * k * k + pad for co, ci, k in layers)
+    master = torch.randn(total, generator=g).to(dev)
+    rows, moff, off, tiles = [], 3, 0, 0
+    for co, ci, k in layers:
+        rows.append([moff, off, off, co, ci, k, tiles, 0])
+        moff += co * ci * k * k + 2
+        off += -(-co * ci * k * k // 128) * 128
+        tiles += -(-co // 32) * -(-ci // 32)
+    assert moff <= total
+    fwd = torch.full((off,), 7.0, dtype=dt, device=dev)
+    bwd = torch.full((off,), 7.0, dtype=dt, device=dev)
+    table = torch.tensor(rows, dtype=torch.int64, device=dev)
+    ops.pack_conv_weights_(master, fwd, bwd, table, tiles)
+    for (mo, o, _, co, ci, k, _, _) in rows:
+        n = co * ci * k * k
+        w = master[mo:mo + n].view(co, ci, k, k)
+        want_f = w.permute(0, 2, 3, 1).contiguous().to(dt)
+        want_b = want_f.flip(1, 2).permute(3, 1, 2, 0).contiguous()
+        assert torch.equal(fwd[o:o + n].view(co, k, k, ci), want_f), (co, ci, k)
+        assert torch.equal(bwd[o:o + n].view(ci, k, k, co), want_b), (co, ci, k)
+        pad_hi = -(-n // 128) * 128
+        assert bool((fwd[o + n:o + pad_hi] == 7.0).all()) and bool((bwd[o + n:o + pad_hi] == 7.0).all())
