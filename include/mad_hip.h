@@ -255,6 +255,17 @@ size_t mad_bias_grad_workspace(int C);
 int mad_bias_grad(const void* dy, int dtype, long rows, int C, float* dbias, void* workspace,
                   size_t workspace_bytes, int accumulate, void* stream);
 
+/* The 3x3 data-gradient convolution (mad_conv3x3_fused without loader transform, bias or residual: x NHWC
+ * (B,H,W,Cin), w (Cout,3,3,Cin) = the layer's weights transposed with flipped taps) whose output y (B,H,W,Cout)
+ * is the gradient reaching h = act(GroupNorm([gx1, gx2])) -- and, from the same launch, the partial sums
+ * mad_gn_bwd_partial would compute from y: gsum (B, (H/16)*(W/16), Cout, 2), one row per 16x16 output tile
+ * (pass that tile count as nsplit_g to mad_gn_bwd_finalize).  gx1 (B,H,W,gC1), gx2 (B,H,W,gC2), gC1 + gC2 = Cout;
+ * gcoef, act, drop_seed, drop_p as in mad_gn_bwd_partial.  Shapes as mad_conv3x3_fused.
+ * Autograd of Conv2d.forward w.r.t. its input followed by GroupNorm/silu backward (model.py:135-166, 341-348). */
+int mad_conv3x3_gn_bwd_sums(const void* x, int Cin, const void* w, void* y, float* gsum, const void* gx1, int gC1,
+                            const void* gx2, int gC2, const float* gcoef, int act, unsigned long long drop_seed,
+                            float drop_p, int dtype, int B, int H, int W, int Cout, void* stream);
+
 /* Backward of h = act(GroupNorm(x)*(1+scale)+shift), in the three passes of the forward.  x is the
  * concatenation of x1 (C1) and x2 (C2), NHWC (B,H,W,.); dy is the gradient with respect to h over all
  * C1+C2 channels; coef is the forward's (a, d) table.  A gradient tensor's resolution mode: 0 = (H,W);

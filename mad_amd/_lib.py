@@ -69,6 +69,8 @@ SIGNATURES = {
     "mad_gn_bwd_apply": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, ctypes.c_ulonglong,
                                  c_float, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p] + [c_int] * 4 +
                          [c_void_p]),
+    "mad_conv3x3_gn_bwd_sums": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int,
+                                        c_void_p, c_int, ctypes.c_ulonglong, ctypes.c_float] + [c_int] * 5 + [c_void_p]),
     "mad_gn_affine_grad": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
     "mad_pack_conv_weights": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, ctypes.c_long, c_int, c_void_p]),
     "mad_conv_wgrad_edge_workspace": (ctypes.c_size_t, [c_int] * 6),

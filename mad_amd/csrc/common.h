@@ -81,6 +81,12 @@ inline bool raise_lds_limit(const void* kernel, int bytes, int* done_for) {
     return true;
 }
 
+// d/du of u*sigmoid(u)
+__device__ __forceinline__ float silu_grad_f(float u) {
+    const float s = __builtin_amdgcn_rcpf(1.0f + __expf(-u));
+    return s * fmaf(u, 1.0f - s, 1.0f);
+}
+
 // Dropout keep-mask from a counter hash: element e of the tensor dropped with `seed` is kept with probability
 // 1-p and scaled by 1/(1-p).  The same (seed, e) gives the same decision in the forward and in the backward.
 // Decisions are drawn for groups of 8 consecutive elements: a two-round hash of the group index gives the

@@ -35,6 +35,12 @@ struct HaloArgs {
     const void* sx1; const void* sx2; const void* sw;
     int SC1, SC2;
     int stream_out;   // output larger than the on-die caches: written with streaming stores
+    // GSTAT form: the output is the gradient dy reaching h = act(GroupNorm([gx1, gx2]) (affine in gcoef)), possibly
+    // dropped out (gdm); `stats` then receives that GroupNorm backward's partial sums (sum g, sum g*x) per tile,
+    // g = dy * keep * act'(a*x + d), instead of the output's own statistics.
+    const void* gx1; const void* gx2; const float* gcoef;
+    int gC1, gact;
+    DropMask gdm;
 };
 
 constexpr int HT = 16;                 // output tile edge
@@ -76,7 +82,7 @@ template <int BN> constexpr int halo_lds_bytes() {
 }
 
 // OUT_NCHW: write the first a.Cout (<= BN) channels as NCHW fp32 with bias (last layer).
-template <typename T, bool FUSE, int WM, int WN, int TN, bool OUT_NCHW, bool SKIP>
+template <typename T, bool FUSE, int WM, int WN, int TN, bool OUT_NCHW, bool SKIP, bool GSTAT>
 __global__ __launch_bounds__(64 * WM * WN, WM * WN / 2) void conv3x3_halo_kernel(HaloArgs a) {
     constexpr int NWAVES = WM * WN, NT = 64 * NWAVES;
     static_assert(NWAVES == 4 || NWAVES == 8, "4 or 8 waves");
@@ -488,13 +494,62 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / 2) void conv3x3_halo_kernel
             Vec16<T> o; o.pack(v);
             if (a.stream_out) o.store_nt(y + m * a.Cout + n0 + ec);     // larger than the caches: do not allocate
             else o.store(y + m * a.Cout + n0 + ec);
-            if (a.stats) {
+            if constexpr (GSTAT) {
+                // sums taken after both halves are stored (below): the accumulators are dead by then
+            } else if (a.stats) {
                 float f[VEC]; o.unpack(f);          // statistics of the values as stored
 #pragma unroll
                 for (int i = 0; i < VEC; ++i) { ssum[i] += f[i]; ssq[i] = fmaf(f[i], f[i], ssq[i]); }
             }
         }
         MAD_STAMP_PHASE(5 + 3 * half)
+    }
+    if constexpr (GSTAT) {
+        // Each thread reads back the gradient chunks it has just stored (its own writes, in program order) together
+        // with the GroupNorm input at the same pixels; with the accumulators dead eight row pairs are in flight
+        // at a time.  g = dy * keep * act'(a*x + d); sums of g and g*x per channel.
+        const int c = n0 + ec;
+        float gca[VEC], gcd[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            gca[i] = a.gcoef[((size_t)b * a.Cout + c + i) * 2];
+            gcd[i] = a.gcoef[((size_t)b * a.Cout + c + i) * 2 + 1];
+        }
+        const T* gsrc; int gcs;
+        if (c < a.gC1) { gsrc = (const T*)a.gx1 + c; gcs = a.gC1; }
+        else { gsrc = (const T*)a.gx2 + (c - a.gC1); gcs = a.Cout - a.gC1; }
+        constexpr int KB = 8;                  // row pairs in flight per batch
+        static_assert((2 * RPT) % KB == 0, "whole batches");
+#pragma unroll 1
+        for (int k0 = 0; k0 < 2 * RPT; k0 += KB) {
+            uint4 xq[KB], gq[KB];
+#pragma unroll
+            for (int k = 0; k < KB; ++k) {
+                const int r = er + (k0 + k) * RPP;
+                const size_t m = ((size_t)b * a.H + ty0 + (r >> 4)) * a.W + tx0 + (r & 15);
+                xq[k] = *reinterpret_cast<const uint4*>(gsrc + m * gcs);
+                gq[k] = *reinterpret_cast<const uint4*>(y + m * a.Cout + c);
+            }
+#pragma unroll
+            for (int k = 0; k < KB; ++k) {
+                const int r = er + (k0 + k) * RPP;
+                const size_t m = ((size_t)b * a.H + ty0 + (r >> 4)) * a.W + tx0 + (r & 15);
+                float f[VEC], xv[VEC];
+                Vec16<T> gr; gr.raw = gq[k]; gr.unpack(f);
+                Vec16<T> xr; xr.raw = xq[k]; xr.unpack(xv);
+                if (a.gdm.thr) {
+                    float keep[VEC];
+                    drop_factors<VEC>(a.gdm, (unsigned long long)m * a.Cout + c, keep);
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) f[i] *= keep[i];
+                }
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) {
+                    const float gi = a.gact ? f[i] * silu_grad_f(fmaf(xv[i], gca[i], gcd[i])) : f[i];
+                    ssum[i] += gi; ssq[i] = fmaf(gi, xv[i], ssq[i]);
+                }
+            }
+        }
     }
     if (a.stats) {
         // reduce the RPP row-groups per channel in a fixed order
@@ -525,15 +580,15 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / 2) void conv3x3_halo_kernel
 #endif
 }
 
-template <typename T, bool FUSE, int WM, int WN, int TN, bool OUT_NCHW, bool SKIP = false>
+template <typename T, bool FUSE, int WM, int WN, int TN, bool OUT_NCHW, bool SKIP = false, bool GSTAT = false>
 static int launch_halo(const HaloArgs& a, hipStream_t s, const char* what) {
     constexpr int lds = halo_lds_bytes<WN * TN * 32>();
     static int lds_dev = -1;
-    MAD_REQUIRE(raise_lds_limit(reinterpret_cast<const void*>(&conv3x3_halo_kernel<T, FUSE, WM, WN, TN, OUT_NCHW, SKIP>),
+    MAD_REQUIRE(raise_lds_limit(reinterpret_cast<const void*>(&conv3x3_halo_kernel<T, FUSE, WM, WN, TN, OUT_NCHW, SKIP, GSTAT>),
                                 lds, &lds_dev),
                 "%s: cannot raise the dynamic LDS limit to %d", what, lds);
     const int grid = a.B * a.tiles_x * a.tiles_y * a.ntiles_n;
-    hipLaunchKernelGGL((conv3x3_halo_kernel<T, FUSE, WM, WN, TN, OUT_NCHW, SKIP>), dim3(grid), dim3(64 * WM * WN), lds, s, a);
+    hipLaunchKernelGGL((conv3x3_halo_kernel<T, FUSE, WM, WN, TN, OUT_NCHW, SKIP, GSTAT>), dim3(grid), dim3(64 * WM * WN), lds, s, a);
     return check_launch(what);
 }
 
@@ -546,10 +601,16 @@ int mad_halo2_try(const void* x1, int C1, const void* x2, int C2, const float* c
                   const float* bias, const void* residual, int res_mode, void* y, float* stats, int B, int H, int W,
                   int Cout, int upsample, hipStream_t stream);
 
+// the GroupNorm whose backward partial sums a launch also produces (GSTAT form of the kernel)
+struct GnFold {
+    const void* gx1; int gC1; const void* gx2; const float* gcoef; int gact; unsigned long long seed; float p;
+};
+
 static int conv3x3_fused_impl(const void* x1, int C1, const void* x2, int C2, const float* coef, int act,
                               const void* w, const float* bias, const void* residual, int res_mode, void* y,
                               float* stats, int dtype, int B, int H, int W, int Cout, int upsample,
-                              const void* sx1, int SC1, const void* sx2, int SC2, const void* sw, void* stream) {
+                              const void* sx1, int SC1, const void* sx2, int SC2, const void* sw, void* stream,
+                              const GnFold* gn = nullptr) {
     MAD_REQUIRE(x1 && w && y, "mad_conv3x3_fused: null pointer");
     MAD_REQUIRE(dtype == MAD_BF16 || dtype == MAD_F32, "mad_conv3x3_fused: bad dtype %d", dtype);
     const int CK = dtype == MAD_BF16 ? 32 : 16;
@@ -564,7 +625,7 @@ static int conv3x3_fused_impl(const void* x1, int C1, const void* x2, int C2, co
     MAD_REQUIRE((size_t)B * H * W < (1u << 31), "mad_conv3x3_fused: tensor too large for 32-bit pixel indices");
     MAD_REQUIRE(res_mode >= MAD_RES_NONE && res_mode <= MAD_RES_DOWN && (res_mode == MAD_RES_NONE || residual),
                 "mad_conv3x3_fused: bad residual mode %d", res_mode);
-    if (dtype == MAD_BF16 && SC1 == 0) {
+    if (dtype == MAD_BF16 && SC1 == 0 && !gn) {
         const int rc = mad_halo2_try(x1, C1, x2, C2, coef, act, w, bias, residual, res_mode, y, stats, B, H, W, Cout,
                                      upsample, (hipStream_t)stream);
         if (rc >= 0) return rc;
@@ -578,6 +639,11 @@ static int conv3x3_fused_impl(const void* x1, int C1, const void* x2, int C2, co
     a.tiles_x = W / HT; a.tiles_y = H / HT;
     a.sx1 = sx1; a.sx2 = SC2 ? sx2 : sx1; a.sw = sw; a.SC1 = SC1; a.SC2 = SC2;
     a.stream_out = (size_t)B * H * W * Cout * (dtype == MAD_BF16 ? 2 : 4) > ((size_t)256 << 20);
+    a.gx1 = a.gx2 = nullptr; a.gcoef = nullptr; a.gC1 = 0; a.gact = 0; a.gdm = make_drop_mask(0, 0.0f);
+    if (gn) {
+        a.gx1 = gn->gx1; a.gx2 = gn->gC1 < Cout ? gn->gx2 : gn->gx1; a.gcoef = gn->gcoef; a.gC1 = gn->gC1;
+        a.gact = gn->gact; a.gdm = make_drop_mask(gn->seed, gn->p);
+    }
     hipStream_t s = (hipStream_t)stream;
     const char* what = "mad_conv3x3_fused";
     // 128 output channels per workgroup unless that leaves the chip (256 CUs, two workgroups each) under-filled:
@@ -597,6 +663,7 @@ static int conv3x3_fused_impl(const void* x1, int C1, const void* x2, int C2, co
     auto run = [&](bool narrow) -> int {
 #define MAD_HALO_DISPATCH(T_, TN_)                                                                    \
     do {                                                                                              \
+        if (gn) return launch_halo<T_, false, 2, 2, TN_, false, false, true>(a, s, what);             \
         if (SC1 > 0)                                                                                  \
             return coef ? launch_halo<T_, true, 2, 2, TN_, false, true>(a, s, what)                   \
                         : launch_halo<T_, false, 2, 2, TN_, false, true>(a, s, what);                 \
@@ -636,6 +703,20 @@ extern "C" int mad_conv3x3_fused_skip(const void* x1, int C1, const void* x2, in
     MAD_REQUIRE(SC1 > 0, "mad_conv3x3_fused_skip: SC1=%d, the projected input needs channels", SC1);
     return conv3x3_fused_impl(x1, C1, x2, C2, coef, act, w, bias, nullptr, MAD_RES_NONE, y, stats, dtype, B, H, W, Cout,
                               0, sx1, SC1, sx2, SC2, sw, stream);
+}
+
+extern "C" int mad_conv3x3_gn_bwd_sums(const void* x, int Cin, const void* w, void* y, float* gsum, const void* gx1,
+                                       int gC1, const void* gx2, int gC2, const float* gcoef, int act,
+                                       unsigned long long drop_seed, float drop_p, int dtype, int B, int H, int W,
+                                       int Cout, void* stream) {
+    MAD_REQUIRE(gsum && gx1 && gcoef, "mad_conv3x3_gn_bwd_sums: null pointer");
+    const int VEC = dtype == MAD_BF16 ? 8 : 4;
+    MAD_REQUIRE(gC1 > 0 && gC2 >= 0 && gC1 + gC2 == Cout && gC1 % VEC == 0 && (gC2 == 0 || gx2),
+                "mad_conv3x3_gn_bwd_sums: the GroupNorm input has %d + %d channels, the gradient %d", gC1, gC2, Cout);
+    MAD_REQUIRE(drop_p >= 0.0f && drop_p < 1.0f, "mad_conv3x3_gn_bwd_sums: p=%f out of [0,1)", (double)drop_p);
+    const GnFold gn = {gx1, gC1, gx2, gcoef, act, drop_seed, drop_p};
+    return conv3x3_fused_impl(x, Cin, nullptr, 0, nullptr, 0, w, nullptr, nullptr, MAD_RES_NONE, y, gsum, dtype, B, H, W,
+                              Cout, 0, nullptr, 0, nullptr, 0, nullptr, stream, &gn);
 }
 
 #ifdef MAD_HALO_STAMPS

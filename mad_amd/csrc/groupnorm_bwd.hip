@@ -43,12 +43,6 @@ __device__ __forceinline__ void load_grad(const T* t, int mode, int b, int y, in
     }
 }
 
-// d/du of u*sigmoid(u)
-__device__ __forceinline__ float silu_grad_f(float u) {
-    const float s = __builtin_amdgcn_rcpf(1.0f + __expf(-u));
-    return s * fmaf(u, 1.0f - s, 1.0f);
-}
-
 struct GnBwdArgs {
     const void* x1; const void* x2; const void* dy; const float* coef;
     int C1, C2, B, H, W, act, dy_mode;

@@ -321,6 +321,34 @@ def conv3x3_fused(x1: Tensor, w: Tensor, bias: Optional[Tensor], coef: Optional[
     return (y, stats) if want_stats else y
 
 
+def conv3x3_dgrad_gn_sums(dy: Tensor, wT: Tensor, gx1: Tensor, gcoef: Tensor, act: bool, gx2: Optional[Tensor] = None,
+                          drop_seed: int = 0, drop_p: float = 0.0):
+    """Data gradient of a 3x3 conv (``wT`` (Cin, 3, 3, Cout): the layer's weights transposed, taps flipped) whose
+    result dh is the gradient reaching h = act(GroupNorm([gx1, gx2])) -- plus, from the same launch, the partial
+    sums (B, tiles, C, 2) of that GroupNorm's backward (pass them to ``gn_backward(gsum=...)``).  Returns (dh, gsum)."""
+    _dev(dy, wT, gx1, gx2, gcoef)
+    B, H, W_, Cin = dy.shape
+    Cout = wT.shape[0]
+    gC1 = gx1.shape[3]
+    gC2 = 0 if gx2 is None else gx2.shape[3]
+    if wT.dtype != dy.dtype or tuple(wT.shape) != (Cout, 3, 3, Cin):
+        raise ValueError(f"conv3x3_dgrad_gn_sums weight {tuple(wT.shape)}/{wT.dtype} does not match gradient {Cin}/{dy.dtype}")
+    if (tuple(gx1.shape[:3]) != (B, H, W_) or (gx2 is not None and tuple(gx2.shape[:3]) != (B, H, W_)) or gC1 + gC2 != Cout
+            or gx1.dtype != dy.dtype or (gx2 is not None and gx2.dtype != dy.dtype)):
+        raise ValueError("conv3x3_dgrad_gn_sums: the GroupNorm input does not have the shape of the data gradient")
+    if gcoef.dtype != torch.float32 or tuple(gcoef.shape) != (B, Cout, 2):
+        raise ValueError("conv3x3_dgrad_gn_sums coef must be fp32 (B, C, 2)")
+    dh = torch.empty((B, H, W_, Cout), dtype=dy.dtype, device=dy.device)
+    gsum = torch.empty((B, (H // 16) * (W_ // 16), Cout, 2), dtype=torch.float32, device=dy.device)
+    end = TIMER.bracket("conv3x3_halo", 2.0 * B * H * W_ * Cout * Cin * 9)
+    check(lib.mad_conv3x3_gn_bwd_sums(_ptr(dy), Cin, _ptr(wT), _ptr(dh), _ptr(gsum), _ptr(gx1), gC1, _ptr(gx2), gC2,
+                                      _ptr(gcoef), int(act), drop_seed, float(drop_p), _dtype_code(dy), B, H, W_, Cout,
+                                      _stream()), "mad_conv3x3_gn_bwd_sums")
+    if end is not None:
+        end.record()
+    return dh, gsum
+
+
 def conv3x3_img8(x1: Tensor, w: Tensor, bias: Optional[Tensor], coef: Optional[Tensor] = None, act: bool = True,
                  x2: Optional[Tensor] = None, residual: Optional[Tensor] = None, res_mode: int = _lib.RES_NONE,
                  want_stats: bool = False):
@@ -524,7 +552,7 @@ def gn_backward(x1: Tensor, dy: Tensor, coef: Tensor, stat1: Tensor, gamma: Tens
                 dy_mode: int = GRAD_SAME, add1: Optional[Tensor] = None, add1_mode: int = GRAD_SAME,
                 add2: Optional[Tensor] = None, add2_mode: int = GRAD_SAME, need_dx: bool = True,
                 drop_seed: int = 0, drop_p: float = 0.0, dgamma: Optional[Tensor] = None,
-                dbeta: Optional[Tensor] = None, accumulate: bool = False):
+                dbeta: Optional[Tensor] = None, accumulate: bool = False, gsum: Optional[Tensor] = None):
     """Backward of h = act(GroupNorm([x1, x2]) * (1 + scale) + shift).
 
     ``coef`` and ``stat1``/``stat2`` are the forward's (a, d) table and statistics partials; ``dy`` is the
@@ -532,16 +560,23 @@ def gn_backward(x1: Tensor, dy: Tensor, coef: Tensor, stat1: Tensor, gamma: Tens
     ``gn_apply(..., drop_seed, drop_p)`` and dy is masked the same way first.  Returns (dx1, dx2, dgamma, dbeta); the
     AdaGN gradients are written into ``dada`` (a view laid out like ``ada``).  ``add1``/``add2`` are further
     gradients reaching x, added into dx.  ``dgamma``/``dbeta`` (fp32 (C,)) receive the affine gradients in place
-    (added when ``accumulate``)."""
-    _dev(x1, x2, dy, coef, stat1, stat2, gamma, beta, add1, add2, dgamma, dbeta)
+    (added when ``accumulate``).  ``gsum`` (fp32 (B, n, C, 2)): the partial sums, when the producer of dy has
+    already computed them (``conv3x3_dgrad_gn_sums``)."""
+    _dev(x1, x2, dy, coef, stat1, stat2, gamma, beta, add1, add2, dgamma, dbeta, gsum)
     B, H, W_, C1 = x1.shape
     C2 = 0 if x2 is None else x2.shape[3]
     C = C1 + C2
     code = _dtype_code(x1)
-    nsg = gn_nsplit(H * W_)
-    gsum = torch.empty((B, nsg, C, 2), dtype=torch.float32, device=x1.device)
-    check(lib.mad_gn_bwd_partial(_ptr(x1), C1, _ptr(x2), C2, _ptr(dy), dy_mode, _ptr(coef), int(act), drop_seed, float(drop_p),
-                                 code, _ptr(gsum), B, H, W_, nsg, _stream()), "mad_gn_bwd_partial")
+    if gsum is not None:
+        if gsum.dtype != torch.float32 or gsum.dim() != 4 or (gsum.shape[0], gsum.shape[2], gsum.shape[3]) != (B, C, 2) \
+                or not gsum.is_contiguous():
+            raise ValueError("gn_backward: gsum must be contiguous fp32 (B, n, C, 2)")
+        nsg = gsum.shape[1]
+    else:
+        nsg = gn_nsplit(H * W_)
+        gsum = torch.empty((B, nsg, C, 2), dtype=torch.float32, device=x1.device)
+        check(lib.mad_gn_bwd_partial(_ptr(x1), C1, _ptr(x2), C2, _ptr(dy), dy_mode, _ptr(coef), int(act), drop_seed,
+                                     float(drop_p), code, _ptr(gsum), B, H, W_, nsg, _stream()), "mad_gn_bwd_partial")
     bcoef = torch.empty((B, C, 4), dtype=torch.float32, device=x1.device)
     dgb = torch.empty((B, 2 * C), dtype=torch.float32, device=x1.device)
     ns1 = stat1.shape[1]

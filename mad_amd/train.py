@@ -138,6 +138,7 @@ class UNetTrainer:
     # ------------------------------------------------------------------ working copies of the weights
     REPACK = os.environ.get("MAD_TRAIN_REPACK", "1") != "0"
     FUSE_SKIP = os.environ.get("MAD_TRAIN_FUSE_SKIP", "1") != "0"
+    FOLD_GN_SUMS = os.environ.get("MAD_TRAIN_FOLD_GN_SUMS", "1") != "0"
 
     def _adopt_pack(self, P: dict) -> None:
         """Move the conv working copies of a freshly built pack into two arenas (forward layout; transposed with
@@ -263,6 +264,19 @@ class UNetTrainer:
         if wT.shape[1] == 3:
             return UNetTrainer._conv3(dy, wT, None, want_stats=False)[0]
         return ops.conv2d(dy, wT, None)
+
+    def _dgrad3_sums(self, dy: Tensor, wT: Tensor, gx1: Tensor, gcoef: Tensor, gx2: Optional[Tensor] = None,
+                     drop_seed: int = 0, drop_p: float = 0.0):
+        """Data gradient of a 3x3 conv whose input was silu(GroupNorm([gx1, gx2])) at the same resolution; returns
+        (dh, partial sums of that GroupNorm's backward, or None when the shape is not covered by the fused launch)."""
+        B, H, W_, C = dy.shape
+        Cg = wT.shape[0]
+        cm = 32 if dy.dtype == torch.bfloat16 else 16
+        vec = 8 if dy.dtype == torch.bfloat16 else 4
+        if (self.FOLD_GN_SUMS and wT.shape[1] == 3 and ops.fused_conv_ok(H, W_, Cg) and C % cm == 0
+                and tuple(gx1.shape[:3]) == (B, H, W_) and gx1.shape[3] % vec == 0):
+            return ops.conv3x3_dgrad_gn_sums(dy, wT, gx1, gcoef, True, gx2=gx2, drop_seed=drop_seed, drop_p=drop_p)
+        return self._dgrad3(dy, wT), None
 
     def _part(self, t: Tensor, part: Optional[Tensor]) -> Tensor:
         return part if part is not None else ops.gn_partial(t)
@@ -407,19 +421,22 @@ class UNetTrainer:
         # conv1 and the AdaGN in front of it
         self._wgrad(f"{n}.conv1.weight", sv.h1, dy, 3, bias=f"{n}.conv1.bias",
                     same_bias=f"{n}.skip.bias" if b.skip_conv else None)
-        dh1 = self._dgrad3(dy, _dgrad_weight(e, "conv1.w"))
+        drop_p = self.dropout if sv.seed is not None else 0.0
+        dh1, gs1 = self._dgrad3_sums(dy, _dgrad_weight(e, "conv1.w"), sv.h, sv.c1, drop_seed=sv.seed or 0, drop_p=drop_p)
         dh, _, dg, db = ops.gn_backward(sv.h, dh1, sv.c1, sv.h_part, e["norm1.g"], e["norm1.b"],
                                         gn_groups(b.out_channels), GN_EPS, act=True, ada=ada_v, ada_stride=ada_total,
-                                        dada=dada_v, drop_seed=sv.seed or 0,
-                                        drop_p=self.dropout if sv.seed is not None else 0.0,
+                                        dada=dada_v, drop_seed=sv.seed or 0, drop_p=drop_p,
                                         dgamma=self.grads[f"{n}.norm1.weight"], dbeta=self.grads[f"{n}.norm1.bias"],
-                                        accumulate=self._accumulating)
+                                        accumulate=self._accumulating, gsum=gs1)
         self._mark(f"{n}.norm1.weight")
         self._mark(f"{n}.norm1.bias")
         # conv0 (input possibly resampled after norm0 + SiLU)
         self._wgrad(f"{n}.conv0.weight", sv.h0, dh, 3, upsample=b.up, bias=f"{n}.conv0.bias")
-        dh0 = self._dgrad3(dh, _dgrad_weight(e, "conv0.w"))
         mode0 = ops.GRAD_FROM_DOUBLE if b.up else (ops.GRAD_FROM_HALF if b.down else ops.GRAD_SAME)
+        if mode0 == ops.GRAD_SAME:
+            dh0, gs0 = self._dgrad3_sums(dh, _dgrad_weight(e, "conv0.w"), sv.x, sv.c0, gx2=sv.skip)
+        else:                                # norm0 runs at the other resolution: its sums need the resampled gradient
+            dh0, gs0 = self._dgrad3(dh, _dgrad_weight(e, "conv0.w")), None
         # the residual branch's gradient w.r.t. the block input
         if b.skip_conv:
             if sv.skip is None:
@@ -447,8 +464,8 @@ class UNetTrainer:
                                             gn_groups(b.in_channels), GN_EPS, act=True, x2=sv.skip,
                                             stat2=sv.skip_part, dy_mode=mode0, add1=dres, add1_mode=res_mode,
                                             add2=add2,
-                                        dgamma=self.grads[f"{n}.norm0.weight"], dbeta=self.grads[f"{n}.norm0.bias"],
-                                        accumulate=self._accumulating)
+                                            dgamma=self.grads[f"{n}.norm0.weight"], dbeta=self.grads[f"{n}.norm0.bias"],
+                                            accumulate=self._accumulating, gsum=gs0)
         self._mark(f"{n}.norm0.weight")
         self._mark(f"{n}.norm0.bias")
         return dx, dskip
@@ -475,11 +492,11 @@ class UNetTrainer:
             self._set("out_conv.weight", ops.conv_wgrad_edge(tape["hact"], False, dpred, True, 3))
         wT = torch.zeros((Cf, 3, 3, pad_c), dtype=dt, device=dev)
         wT[..., :Co] = P["out.w"].flip(1, 2).permute(3, 1, 2, 0).to(dt)
-        dhact = self._dgrad3(dp, wT)
+        dhact, gs = self._dgrad3_sums(dp, wT, tape["h_last"], tape["c_out"])
         dh, _, dg, db = ops.gn_backward(tape["h_last"], dhact, tape["c_out"], tape["h_last_part"], P["out_norm.g"],
                                         P["out_norm.b"], gn_groups(Cf), GN_EPS, act=True,
                                         dgamma=self.grads["out_norm.weight"], dbeta=self.grads["out_norm.bias"],
-                                        accumulate=self._accumulating)
+                                        accumulate=self._accumulating, gsum=gs)
         self._mark("out_norm.weight")
         self._mark("out_norm.bias")
 

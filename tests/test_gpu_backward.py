@@ -234,3 +234,57 @@ def test_pack_conv_weights_ragged_layers(dev, dt):
         assert torch.equal(bwd[o:o + n].view(ci, k, k, co), want_b), (co, ci, k)
         pad_hi = -(-n // 128) * 128
         assert bool((fwd[o + n:o + pad_hi] == 7.0).all()) and bool((bwd[o + n:o + pad_hi] == 7.0).all())
+
+
+DGRAD_SUMS_CASES = [
+    # B, H, W, Cdy (channels of the incoming gradient), C1, C2 (GroupNorm input channels), dropout p
+    (2, 32, 32, 64, 64, 0, 0.1),         # narrow form, dropout mask rebuilt in the epilogue
+    (2, 16, 32, 32, 64, 64, 0.0),        # GroupNorm over a concatenation, non-square
+    (1, 32, 32, 64, 192, 0, 0.0),        # odd multiple of 64 channels
+    (3, 32, 32, 96, 96, 32, 0.1),        # 128-channel tile whose source changes inside the tile
+    (9, 32, 32, 32, 256, 0, 0.0),        # enough tiles for the wide form
+    (2, 64, 64, 128, 128, 0, 0.1),       # several tile rows per image
+]
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("case", DGRAD_SUMS_CASES)
+def test_conv_dgrad_with_gn_backward_sums(dev, case, dt):
+    """The data-gradient conv that also emits the GroupNorm backward's partial sums: its output equals the plain
+    conv's, and gn_backward fed with its sums equals gn_backward computing the sums itself from that output."""
+    from mad_amd import ops
+    B, H, W, Cdy, C1, C2, p = case
+    C, seed, groups = C1 + C2, 0x51f15eed, 32
+    dy = _nhwc(_rand((B, Cdy, H, W), 1), dt, dev)
+    wT = (_rand((C, 3, 3, Cdy), 2) / math.sqrt(9 * Cdy)).to(dt).to(dev)
+    x1 = _nhwc(_rand((B, C1, H, W), 3, 1.3), dt, dev)
+    x2 = _nhwc(_rand((B, C2, H, W), 4, 0.7), dt, dev) if C2 else None
+    gamma, beta = (1 + 0.2 * _rand((C,), 5)).to(dev), (0.2 * _rand((C,), 6)).to(dev)
+    st1, st2 = ops.gn_partial(x1), (ops.gn_partial(x2) if C2 else None)
+    coef = ops.gn_finalize(st1, H * W, gamma, beta, groups, 1e-5, partial2=st2)
+    dh, gsum = ops.conv3x3_dgrad_gn_sums(dy, wT, x1, coef, True, gx2=x2, drop_seed=seed, drop_p=p)
+    plain = ops.conv3x3_fused(dy, wT, None, coef=None)
+    assert gsum.shape == (B, (H // 16) * (W // 16), C, 2)
+    if dt == torch.float32:
+        assert torch.equal(dh, plain)
+    else:                                            # the plain launch may run on the persistent form (two roundings)
+        assert rel_err(dh.float().cpu(), plain.float().cpu()) < 8e-3
+    kw = dict(x2=x2, stat2=st2, drop_seed=seed, drop_p=p)
+    want = ops.gn_backward(x1, dh, coef, st1, gamma, beta, groups, 1e-5, True, **kw)
+    got = ops.gn_backward(x1, dh, coef, st1, gamma, beta, groups, 1e-5, True, gsum=gsum, **kw)
+    tol = 2e-5 if dt == torch.float32 else 4e-3      # the same terms summed in another order (bf16: dx rounded once more)
+    for g, w_, name in zip(got, want, ("dx1", "dx2", "dgamma", "dbeta")):
+        if w_ is None:
+            assert g is None
+            continue
+        assert rel_err(g.float().cpu(), w_.float().cpu()) < tol, name
+    # the sums themselves against a per-tile reduction of the same quantity in torch
+    xcat = torch.cat([x1, x2], dim=-1).float() if C2 else x1.float()
+    keep = ops.dropout_(torch.ones_like(xcat), seed, p) if p > 0 else torch.ones_like(xcat)
+    u = xcat * coef[:, None, None, :, 0] + coef[:, None, None, :, 1]
+    sg = torch.sigmoid(u)
+    g = dh.float() * keep * (sg * (1 + u * (1 - sg)))
+    def tiles(t):
+        return t.view(B, H // 16, 16, W // 16, 16, C).sum((2, 4)).reshape(B, -1, C)
+    ref = torch.stack([tiles(g), tiles(g * xcat)], dim=-1)
+    assert rel_err(gsum.cpu(), ref.cpu()) < 2e-5
