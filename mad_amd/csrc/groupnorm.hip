@@ -83,12 +83,25 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict
     const int C = C1 + C2, cpg = C / groups;
     const int max_ns = nsplit1 > nsplit2 ? nsplit1 : nsplit2;
     double s = 0.0, q = 0.0;
-    for (int it = lane; it < cpg * max_ns; it += 64) {
-        const int c = g * cpg + it / max_ns, sp = it % max_ns;
-        const float* p = nullptr;
-        if (c < C1) { if (sp < nsplit1) p = partial1 + (((size_t)b * nsplit1 + sp) * C1 + c) * 2; }
-        else { if (sp < nsplit2) p = partial2 + (((size_t)b * nsplit2 + sp) * C2 + (c - C1)) * 2; }
-        if (p) { s += (double)p[0]; q += (double)p[1]; }
+    // four independent loads in flight per lane (the sums are accumulated in the order of a one-at-a-time loop)
+    const int total = cpg * max_ns;
+    for (int it0 = lane; it0 < total; it0 += 256) {
+        float2 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int it = it0 + 64 * u;
+            const int itc = it < total ? it : 0;
+            const int c = g * cpg + itc / max_ns, sp = itc % max_ns;
+            const bool first = c < C1;
+            const int ns = first ? nsplit1 : nsplit2;
+            const int spc = sp < ns ? sp : ns - 1;
+            const float* p = first ? partial1 + (((size_t)b * nsplit1 + spc) * C1 + c) * 2
+                                   : partial2 + (((size_t)b * nsplit2 + spc) * C2 + (c - C1)) * 2;
+            v[u] = *reinterpret_cast<const float2*>(p);
+            if (it >= total || sp >= ns) v[u] = make_float2(0.0f, 0.0f);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { s += (double)v[u].x; q += (double)v[u].y; }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) { s += __shfl_xor(s, off); q += __shfl_xor(q, off); }

@@ -135,12 +135,25 @@ __global__ __launch_bounds__(64) void gn_bwd_finalize_kernel(GnBwdFinArgs a) {
     const int C = a.C1 + a.C2, cpg = C / a.groups;
     const int max_ns = a.ns1 > a.ns2 ? a.ns1 : a.ns2;
     double s = 0.0, q = 0.0;
-    for (int it = lane; it < cpg * max_ns; it += 64) {
-        const int c = g * cpg + it / max_ns, sp = it % max_ns;
-        const float* p = nullptr;
-        if (c < a.C1) { if (sp < a.ns1) p = a.stat1 + (((size_t)b * a.ns1 + sp) * a.C1 + c) * 2; }
-        else { if (sp < a.ns2) p = a.stat2 + (((size_t)b * a.ns2 + sp) * a.C2 + (c - a.C1)) * 2; }
-        if (p) { s += (double)p[0]; q += (double)p[1]; }
+    // four independent loads in flight per lane (the sums are accumulated in the order of a one-at-a-time loop)
+    const int total = cpg * max_ns;
+    for (int it0 = lane; it0 < total; it0 += 256) {
+        float2 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int it = it0 + 64 * u;
+            const int itc = it < total ? it : 0;
+            const int c = g * cpg + itc / max_ns, sp = itc % max_ns;
+            const bool first = c < a.C1;
+            const int ns = first ? a.ns1 : a.ns2;
+            const int spc = sp < ns ? sp : ns - 1;
+            const float* p = first ? a.stat1 + (((size_t)b * a.ns1 + spc) * a.C1 + c) * 2
+                                   : a.stat2 + (((size_t)b * a.ns2 + spc) * a.C2 + (c - a.C1)) * 2;
+            v[u] = *reinterpret_cast<const float2*>(p);
+            if (it >= total || sp >= ns) v[u] = make_float2(0.0f, 0.0f);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { s += (double)v[u].x; q += (double)v[u].y; }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) { s += __shfl_xor(s, off); q += __shfl_xor(q, off); }
@@ -150,27 +163,38 @@ __global__ __launch_bounds__(64) void gn_bwd_finalize_kernel(GnBwdFinArgs a) {
     if (var < 0.0) var = 0.0;
     const float mean_f = (float)mean, rstd_f = (float)(1.0 / sqrt(var + (double)a.eps));
 
+    // gradient sums per channel: the lanes share the rows of partial sums of one channel at a time (a row per
+    // 16x16 tile when the data-gradient conv produced them), butterfly-reduced so that every lane holds the totals
     double Ag = 0.0, Bg = 0.0;
-    for (int i = lane; i < cpg; i += 64) {
+    for (int i = 0; i < cpg; ++i) {
         const int c = g * cpg + i;
         double S1 = 0.0, S2 = 0.0;
-        for (int sp = 0; sp < a.nsg; ++sp) {
-            const float* p = a.gsum + (((size_t)b * a.nsg + sp) * C + c) * 2;
-            S1 += (double)p[0]; S2 += (double)p[1];
+        for (int sp0 = lane; sp0 < a.nsg; sp0 += 256) {
+            float2 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int sp = sp0 + 64 * u;
+                v[u] = *reinterpret_cast<const float2*>(a.gsum + (((size_t)b * a.nsg + (sp < a.nsg ? sp : 0)) * C + c) * 2);
+                if (sp >= a.nsg) v[u] = make_float2(0.0f, 0.0f);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { S1 += (double)v[u].x; S2 += (double)v[u].y; }
         }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { S1 += __shfl_xor(S1, off); S2 += __shfl_xor(S2, off); }
         const double sc = a.ada ? 1.0 + (double)a.ada[(size_t)b * a.ada_stride + c] : 1.0;
         const double gam = a.gamma[c], bet = a.beta[c];
         const double Gx = (double)rstd_f * (S2 - (double)mean_f * S1);
-        a.dgb[(size_t)b * 2 * C + c] = (float)(sc * Gx);
-        a.dgb[(size_t)b * 2 * C + C + c] = (float)(sc * S1);
-        if (a.dada) {
-            a.dada[(size_t)b * a.ada_stride + c] = (float)(gam * Gx + bet * S1);
-            a.dada[(size_t)b * a.ada_stride + C + c] = (float)S1;
+        if (lane == 0) {
+            a.dgb[(size_t)b * 2 * C + c] = (float)(sc * Gx);
+            a.dgb[(size_t)b * 2 * C + C + c] = (float)(sc * S1);
+            if (a.dada) {
+                a.dada[(size_t)b * a.ada_stride + c] = (float)(gam * Gx + bet * S1);
+                a.dada[(size_t)b * a.ada_stride + C + c] = (float)S1;
+            }
         }
         Ag += sc * gam * S1; Bg += sc * gam * Gx;
     }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { Ag += __shfl_xor(Ag, off); Bg += __shfl_xor(Bg, off); }
     const double qg = -(double)rstd_f * rstd_f * Bg / n;
     const double rg = -(double)rstd_f * Ag / n - (double)mean_f * qg;
     for (int i = lane; i < cpg; i += 64) {
