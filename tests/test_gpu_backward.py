@@ -288,3 +288,29 @@ def test_conv_dgrad_with_gn_backward_sums(dev, case, dt):
         return t.view(B, H // 16, 16, W // 16, 16, C).sum((2, 4)).reshape(B, -1, C)
     ref = torch.stack([tiles(g), tiles(g * xcat)], dim=-1)
     assert rel_err(gsum.cpu(), ref.cpu()) < 2e-5
+
+
+def test_conv_dgrad_gn_sums_streaming_output(dev):
+    """A gradient tensor larger than the on-die caches is written with streaming stores; the sums taken from the
+    read-back of those stores still equal a per-tile reduction of the stored tensor."""
+    from mad_amd import ops
+    B, H, W, Cdy, C = 3, 512, 512, 32, 256                # dh: 403 MB in bf16
+    dt = torch.bfloat16
+    g = torch.Generator(device=dev).manual_seed(11)
+    dy = torch.randn((B, H, W, Cdy), generator=g, device=dev).to(dt)
+    wT = (torch.randn((C, 3, 3, Cdy), generator=g, device=dev) / math.sqrt(9 * Cdy)).to(dt)
+    x = (1.3 * torch.randn((B, H, W, C), generator=g, device=dev)).to(dt)
+    gamma, beta = torch.ones(C, device=dev), torch.zeros(C, device=dev)
+    st = ops.gn_partial(x)
+    coef = ops.gn_finalize(st, H * W, gamma, beta, 32, 1e-5)
+    dh, gsum = ops.conv3x3_dgrad_gn_sums(dy, wT, x, coef, True)
+    assert dh.numel() * 2 > (256 << 20)
+    ref = torch.empty_like(gsum)
+    for b in range(B):                                   # per image: keeps the fp32 temporaries small
+        xb = x[b].float()
+        u = xb * coef[b, :, 0] + coef[b, :, 1]
+        sg = torch.sigmoid(u)
+        gb = dh[b].float() * (sg * (1 + u * (1 - sg)))
+        t = lambda v: v.view(H // 16, 16, W // 16, 16, C).sum((1, 3)).reshape(-1, C)
+        ref[b, :, :, 0], ref[b, :, :, 1] = t(gb), t(gb * xb)
+    assert rel_err(gsum.cpu(), ref.cpu()) < 2e-5
