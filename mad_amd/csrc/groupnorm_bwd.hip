@@ -166,34 +166,48 @@ __global__ __launch_bounds__(64) void gn_bwd_finalize_kernel(GnBwdFinArgs a) {
     // gradient sums per channel: the lanes share the rows of partial sums of one channel at a time (a row per
     // 16x16 tile when the data-gradient conv produced them), butterfly-reduced so that every lane holds the totals
     double Ag = 0.0, Bg = 0.0;
-    for (int i = 0; i < cpg; ++i) {
-        const int c = g * cpg + i;
-        double S1 = 0.0, S2 = 0.0;
+    constexpr int CB = 4;                      // channels whose rows are requested together
+    for (int i0 = 0; i0 < cpg; i0 += CB) {
+        double S1[CB], S2[CB];
+#pragma unroll
+        for (int k = 0; k < CB; ++k) S1[k] = S2[k] = 0.0;
         for (int sp0 = lane; sp0 < a.nsg; sp0 += 256) {
-            float2 v[4];
+            float2 v[CB][4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int sp = sp0 + 64 * u;
-                v[u] = *reinterpret_cast<const float2*>(a.gsum + (((size_t)b * a.nsg + (sp < a.nsg ? sp : 0)) * C + c) * 2);
-                if (sp >= a.nsg) v[u] = make_float2(0.0f, 0.0f);
+            for (int k = 0; k < CB; ++k) {
+                const int c = g * cpg + (i0 + k < cpg ? i0 + k : i0);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int sp = sp0 + 64 * u;
+                    v[k][u] = *reinterpret_cast<const float2*>(a.gsum + (((size_t)b * a.nsg + (sp < a.nsg ? sp : 0)) * C + c) * 2);
+                    if (sp >= a.nsg) v[k][u] = make_float2(0.0f, 0.0f);
+                }
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { S1 += (double)v[u].x; S2 += (double)v[u].y; }
+            for (int k = 0; k < CB; ++k)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { S1[k] += (double)v[k][u].x; S2[k] += (double)v[k][u].y; }
         }
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) { S1 += __shfl_xor(S1, off); S2 += __shfl_xor(S2, off); }
-        const double sc = a.ada ? 1.0 + (double)a.ada[(size_t)b * a.ada_stride + c] : 1.0;
-        const double gam = a.gamma[c], bet = a.beta[c];
-        const double Gx = (double)rstd_f * (S2 - (double)mean_f * S1);
-        if (lane == 0) {
-            a.dgb[(size_t)b * 2 * C + c] = (float)(sc * Gx);
-            a.dgb[(size_t)b * 2 * C + C + c] = (float)(sc * S1);
-            if (a.dada) {
-                a.dada[(size_t)b * a.ada_stride + c] = (float)(gam * Gx + bet * S1);
-                a.dada[(size_t)b * a.ada_stride + C + c] = (float)S1;
+        for (int k = 0; k < CB; ++k) {
+            if (i0 + k >= cpg) break;
+            const int c = g * cpg + i0 + k;
+            double T1 = S1[k], T2 = S2[k];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) { T1 += __shfl_xor(T1, off); T2 += __shfl_xor(T2, off); }
+            const double sc = a.ada ? 1.0 + (double)a.ada[(size_t)b * a.ada_stride + c] : 1.0;
+            const double gam = a.gamma[c], bet = a.beta[c];
+            const double Gx = (double)rstd_f * (T2 - (double)mean_f * T1);
+            if (lane == 0) {
+                a.dgb[(size_t)b * 2 * C + c] = (float)(sc * Gx);
+                a.dgb[(size_t)b * 2 * C + C + c] = (float)(sc * T1);
+                if (a.dada) {
+                    a.dada[(size_t)b * a.ada_stride + c] = (float)(gam * Gx + bet * T1);
+                    a.dada[(size_t)b * a.ada_stride + C + c] = (float)T1;
+                }
             }
+            Ag += sc * gam * T1; Bg += sc * gam * Gx;
         }
-        Ag += sc * gam * S1; Bg += sc * gam * Gx;
     }
     const double qg = -(double)rstd_f * rstd_f * Bg / n;
     const double rg = -(double)rstd_f * Ag / n - (double)mean_f * qg;
