@@ -97,6 +97,10 @@ def _load() -> ctypes.CDLL:
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `make -C mad_amd/csrc` (or "
             "`python -c 'import __graft_entry__ as g; g.build()'`). mad_amd has no CPU fallback.")
+    # torch ships its own HIP runtime: it must be in the process before this library is, so that the kernels
+    # registered here and the streams / allocations torch hands over belong to ONE runtime (loaded the other way
+    # round, launches fail with "no ROCm-capable device is detected")
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the library lacks a declared symbol

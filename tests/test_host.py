@@ -167,3 +167,17 @@ def test_reference_format_checkpoint_loads(tmp_path):
     torch.save({"ema_state_dict": {"shadow_params": [ema[n] for n in names[:-1]]}}, path)
     with pytest.raises(AssertionError):
         load_checkpoint(m2, path)
+
+
+def test_library_import_brings_torch_runtime_first():
+    """Importing the binding in a fresh interpreter, before anything imported torch, must leave torch's own HIP
+    runtime in the process ahead of the library: the other order gives two runtimes and launches that fail."""
+    import subprocess
+    import sys
+    code = ("import sys; import mad_amd._lib as L; assert 'torch' in sys.modules; "
+            "maps = open('/proc/self/maps').read(); "
+            "libs = [l.split()[-1] for l in maps.splitlines() if 'libamdhip64' in l]; "
+            "assert libs and all('/torch/' in p for p in libs), sorted(set(libs)); print('ok')")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip() == "ok", out.stderr[-2000:]
