@@ -6,8 +6,20 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 One "step" = one full `domain_translation` of a batch of --batch synthetic faces per GPU
-(2*S-1 denoiser evaluations plus the sampler updates).  Rank 0 prints ONE JSON line.  Each rank
-processes its own batch (independent images, no data-path collective): weak scaling.
+(2*S-1 denoiser evaluations plus the sampler updates): about half a minute at the headline size.  Rank 0
+prints ONE JSON line.  Each rank processes its own batch (independent images, no data-path collective):
+weak scaling.
+
+Time budget.  A whole run is meant to finish in well under ten minutes, so --steps is a CAP: after the
+warm-up the cost of one step is estimated from the warm-up's measured time per denoiser evaluation, and
+the run times exactly min(K, what fits --time-budget) full steps (never fewer than one; all ranks agree on
+the number).  The line reports `steps` = the steps timed and `steps_requested` = K.  Warm-up steps run the
+same loop on a shortened schedule (--warmup-num-of-step evaluations each way: the same kernels, shapes and
+allocations per evaluation), and the first one also allocates and frees the full-size noise slab so the
+timed steps find it in the allocator's cache.
+
+Started as a plain process with --gpus N > 1 and no rendezvous variables, it starts its N ranks itself
+(torch.distributed.run as a child process) before anything touches the GPU.
 """
 import argparse
 import json
@@ -15,7 +27,9 @@ import os
 import sys
 import time
 
-import torch
+T_PROCESS_START = time.time()
+
+import torch  # noqa: E402
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 if REPO not in sys.path:
@@ -42,6 +56,12 @@ def parse_args():
     p.add_argument("--cpu-evals", type=int, default=40, help="denoiser evaluations in the CPU sample")
     p.add_argument("--profile-every", type=int, default=100,
                    help="bracket the MFMA kernels of every n-th denoiser evaluation with stream events")
+    p.add_argument("--time-budget", type=float, default=0.0,
+                   help="seconds for the timed steps; 0: what is left of --total-budget after start-up and warm-up, "
+                        "minus the time the lines after the timed region take")
+    p.add_argument("--total-budget", type=float, default=480.0, help="seconds for the whole run (default budget rule)")
+    p.add_argument("--warmup-num-of-step", type=int, default=6,
+                   help="start_from_step of the warm-up translations (same kernels and shapes, shorter schedule)")
     return p.parse_args()
 
 
@@ -128,12 +148,15 @@ def main():
         sys.argv = [sys.argv[0], "--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup),
                     "--config", args.config, "--precision", args.precision] + (["--no-cpu-baseline"] if args.no_cpu_baseline else [])
         return bench_train.main()
+    from mad_amd.launch import needs_relaunch, relaunch_per_gpu
+    if needs_relaunch(args.gpus):
+        # a plain `python bench.py --gpus N`: one child launcher, N ranks; this process never touches the GPU
+        raise SystemExit(relaunch_per_gpu(os.path.abspath(__file__), sys.argv[1:], args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 with torch.distributed.run (one process per GPU)")
+        raise SystemExit(f"--gpus {args.gpus} does not match the {world} ranks this process was started with")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
@@ -185,24 +208,54 @@ def main():
         from mad_amd.translation import MAX_STEP
         S = MAX_STEP                                   # the transfer loop starts at its longest component step
 
-    def one_step():
+    from mad_amd.translation import COMP_INFO, DEFAULT_COMP_SETUP
+
+    def one_step(s_run=None):
+        """One batch translated; `s_run` shortens the schedule (warm-up only)."""
         if args.workload == "transfer":
+            setup = DEFAULT_COMP_SETUP
+            if s_run is not None:      # same component order, steps scaled down to the short schedule
+                setup = {c: COMP_INFO(ci.scale, max(2, ci.step * s_run // S)) for c, ci in DEFAULT_COMP_SETUP.items()}
             return td.image_translation(model, model, images, images, 1, 0, source_parsing_mask=maps, use_cam=True,
-                                        inpainting=True, inverse_image=guides)
+                                        inpainting=True, inverse_image=guides, comp_weight_step=setup)
         return td.domain_translation(model, model, images, source_class_label=0, target_class_label=1,
-                                     parsing_mask=maps, start_from_step=S)
+                                     parsing_mask=maps, start_from_step=S if s_run is None else s_run)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        one_step()
+    # ---- warm-up: short schedules; the first also brings the full-size noise slab into the allocator's cache
+    s_warm = max(2, min(S, args.warmup_num_of_step))
+    per_eval = None
+    for i in range(args.warmup):
+        if i == 0:
+            slab = torch.empty((S, B, 3, R, R), dtype=torch.float32, device=dev)
+            del slab
+        torch.cuda.synchronize()
+        tw = time.perf_counter()
+        one_step(s_warm)
+        torch.cuda.synchronize()
+        if i > 0 or args.warmup == 1:
+            per_eval = (time.perf_counter() - tw) / (2 * s_warm - 1)
+    # ---- how many full steps fit the budget (a cap on --steps; every rank must run the same number)
+    steps = max(1, args.steps)
+    budget = args.time_budget
+    if budget <= 0:
+        after = 10.0 + (0.0 if (args.no_cpu_baseline or world > 1) else 30.0)   # lines after the timed region
+        budget = args.total_budget - (time.time() - T_PROCESS_START) - after
+    if per_eval is not None:
+        est_step = per_eval * (2 * S - 1)
+        steps = max(1, min(steps, int(budget / est_step)))
+    if world > 1:
+        t = torch.tensor([steps], device=dev, dtype=torch.int64)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        steps = int(t.item())
     barrier()
     timed[0] = True
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         out = one_step()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -217,7 +270,7 @@ def main():
     if rank == 0:
         flops_img_eval = spec.flops_per_image()["total"]
         evals = 2 * S - 1
-        images_total = world * B * args.steps
+        images_total = world * B * steps
         value = images_total / elapsed
         # dominant kernel = the MFMA kernel with the largest share of the sampled time
         mfma = {k: v for k, v in kern.items() if v["ms"] > 0}
@@ -242,8 +295,9 @@ def main():
                        if R == 256 else f"translated images/sec @{R}x{R}, fixed-step inversion+denoise")
                       if args.workload == "removal" else
                       f"translated images/sec @{R}x{R}, makeup transfer (inpainting + component masks)",
-            "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "value": value, "unit": "images/s", "n_gpus": world, "steps": steps, "steps_requested": args.steps,
+            "warmup": args.warmup, "warmup_num_of_step": s_warm if args.warmup else None,
+            "time_budget_s": round(budget, 1), "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": f"{os.path.basename(args.config)} "
                                    + ("makeup removal (noise encoding + regeneration), " if args.workload == "removal"
@@ -252,7 +306,7 @@ def main():
                                    + f"DDPM 1000-step table, start_from_step={S} ({evals} denoiser evaluations per "
                                    f"image), batch {B} per GPU, random-init (seeded) weights",
                        "batch_per_gpu": B, "num_of_step": S, "resolution": R, "parallelism": f"dp{world}",
-                       "denoiser_evals_per_s": world * B * args.steps * evals / elapsed / B,
+                       "denoiser_evals_per_s": world * steps * evals / elapsed,
                        "gflop_per_image_per_eval": flops_img_eval / 1e9},
             "mfma_util_end_to_end": value * flops_img_eval * evals / 1e12 / (PEAK_BF16_TFLOPS * world),
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",

@@ -118,8 +118,12 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world == 1 and args.gpus > 1:
-        raise SystemExit("launch N>1 with torch.distributed.run (one process per GPU)")
+    from mad_amd.launch import needs_relaunch, relaunch_per_gpu
+    if needs_relaunch(args.gpus):
+        # a plain `python bench_train.py --gpus N`: one child launcher, N ranks; this process never touches the GPU
+        raise SystemExit(relaunch_per_gpu(os.path.abspath(__file__), sys.argv[1:], args.gpus))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} does not match the {world} ranks this process was started with")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist

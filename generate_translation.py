@@ -143,6 +143,9 @@ def main(argv=None):
             p.start()
         for p in procs:
             p.join()
+        failed = [(i, p.exitcode) for i, p in enumerate(procs) if p.exitcode != 0]
+        if failed:          # a worker that crashed must not look like a finished shard
+            raise SystemExit(f"worker(s) failed (index, exit code): {failed}")
 
 
 if __name__ == "__main__":

@@ -596,11 +596,6 @@ static int launch_halo(const HaloArgs& a, hipStream_t s, const char* what) {
 
 using namespace mad;
 
-// role-split persistent form for the large bf16 layers (conv_halo2.hip); -1 = shape not covered
-int mad_halo2_try(const void* x1, int C1, const void* x2, int C2, const float* coef, int act, const void* w,
-                  const float* bias, const void* residual, int res_mode, void* y, float* stats, int B, int H, int W,
-                  int Cout, int upsample, hipStream_t stream);
-
 // the GroupNorm whose backward partial sums a launch also produces (GSTAT form of the kernel)
 struct GnFold {
     const void* gx1; int gC1; const void* gx2; const float* gcoef; int gact; unsigned long long seed; float p;
@@ -625,11 +620,6 @@ static int conv3x3_fused_impl(const void* x1, int C1, const void* x2, int C2, co
     MAD_REQUIRE((size_t)B * H * W < (1u << 31), "mad_conv3x3_fused: tensor too large for 32-bit pixel indices");
     MAD_REQUIRE(res_mode >= MAD_RES_NONE && res_mode <= MAD_RES_DOWN && (res_mode == MAD_RES_NONE || residual),
                 "mad_conv3x3_fused: bad residual mode %d", res_mode);
-    if (dtype == MAD_BF16 && SC1 == 0 && !gn) {
-        const int rc = mad_halo2_try(x1, C1, x2, C2, coef, act, w, bias, residual, res_mode, y, stats, B, H, W, Cout,
-                                     upsample, (hipStream_t)stream);
-        if (rc >= 0) return rc;
-    }
     HaloArgs a;
     a.x1 = x1; a.x2 = C2 ? x2 : x1; a.w = w; a.bias = bias; a.coef = coef; a.residual = residual; a.y = y;
     a.stats = stats;

@@ -364,7 +364,9 @@ class Denoiser(nn.Module):
         return self.unet.spec
 
     def forward(self, x: Tensor, time: Tensor, text=None, class_labels: Optional[Tensor] = None) -> Tensor:
-        time = torch.as_tensor(time, device=x.device).to(torch.float32).reshape(-1)
+        # cast on the side the timestep lives on: a host timestep becomes one small upload, not an upload
+        # plus a conversion kernel per evaluation
+        time = torch.as_tensor(time).to(torch.float32).reshape(-1).to(x.device)
         if self.graph_replay and x.is_cuda and not torch.cuda.is_current_stream_capturing():
             return self._replay(x, time, class_labels)
         return self.unet(x, time, class_labels)[0]

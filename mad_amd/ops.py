@@ -87,8 +87,10 @@ TIMER = KernelTimer()
 def sampler_update(coef: SamplerCoef, model_output: Tensor, sample: Tensor,
                    noise: Optional[Tensor] = None, original: Optional[Tensor] = None,
                    mask: Optional[Tensor] = None, next_sample: Optional[Tensor] = None,
-                   want_x0: bool = False):
-    _dev(model_output, sample, noise, original, mask, next_sample)
+                   want_x0: bool = False, out: Optional[Tensor] = None):
+    """One pass of the sampler kernel.  ``out`` (fp32, the sample's shape, contiguous) receives the result in
+    place of a fresh tensor -- the noise-encoding loop passes a slice of its step-major slab."""
+    _dev(model_output, sample, noise, original, mask, next_sample, out)
     for t in (model_output, sample, noise, original, next_sample):
         if t is not None and (t.dtype != torch.float32 or t.shape != sample.shape):
             raise ValueError("sampler tensors must be fp32 and share the sample's shape")
@@ -98,7 +100,10 @@ def sampler_update(coef: SamplerCoef, model_output: Tensor, sample: Tensor,
         if mask.dtype != torch.float32 or mask.numel() not in (H * W, B * H * W):
             raise ValueError(f"mask must be fp32 with H*W or B*H*W elements, got {tuple(mask.shape)}")
         mask_batch = mask.numel() // (H * W)
-    out = torch.empty_like(sample)
+    if out is None:
+        out = torch.empty_like(sample)
+    elif out.dtype != torch.float32 or out.shape != sample.shape:
+        raise ValueError("sampler_update: out must be fp32 with the sample's shape")
     x0 = torch.empty_like(sample) if want_x0 else None
     check(lib.mad_sampler_update(coef, _ptr(model_output), _ptr(sample), _ptr(noise), _ptr(original),
                                  _ptr(mask), _ptr(next_sample), _ptr(out), _ptr(x0), B, C, H, W,

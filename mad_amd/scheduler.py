@@ -189,12 +189,12 @@ class CustomDDPMScheduler(_SchedulerBase):
         return SchedulerOutput(prev_sample=prev, pred_original_sample=x0)
 
     def compute_eps(self, model_output: Tensor, timestep, sample: Tensor, next_sample: Tensor,
-                    *args, **kwargs) -> Tensor:
+                    *args, out: Optional[Tensor] = None, **kwargs) -> Tensor:
         assert timestep > 0, "computing eps for ddpm is only available for t > 0"
         c = self._coef(int(timestep), _lib.OP_COMPUTE_EPS)
         c.eps_div = c.std if c.std > 0 else 1.0
         return ops.sampler_update(c, model_output.contiguous(), sample.contiguous(),
-                                  next_sample=next_sample.contiguous())
+                                  next_sample=next_sample.contiguous(), out=out)
 
     def ddim_inverse_step(self, model_output: Tensor, timestep, sample: Tensor, return_dict: bool = True,
                           return_pred_original: bool = False):
@@ -249,12 +249,12 @@ class CustomDDIMScheduler(_SchedulerBase):
         return SchedulerOutput(prev_sample=prev, pred_original_sample=x0)
 
     def compute_eps(self, model_output: Tensor, timestep, sample: Tensor, next_sample: Tensor,
-                    eta: float = 0.1) -> Tensor:
+                    eta: float = 0.1, out: Optional[Tensor] = None) -> Tensor:
         self._ready()
         c = self._coef(int(timestep), _lib.OP_COMPUTE_EPS, eta)
         c.eps_div = c.std if eta > 0 else 1.0
         return ops.sampler_update(c, model_output.contiguous(), sample.contiguous(),
-                                  next_sample=next_sample.contiguous())
+                                  next_sample=next_sample.contiguous(), out=out)
 
     def ddim_inverse_step(self, model_output: Tensor, timestep, sample: Tensor, return_dict: bool = True,
                           return_pred_original: bool = False):

@@ -86,6 +86,7 @@ class UNetTrainer:
         self.step_count = 0
         self.seed = seed
         self._drop_calls = 0
+        self._micro_index = 0
         self._accumulating = False
         self.micro_batches = 0
         params = list(unet.named_parameters())
@@ -300,7 +301,8 @@ class UNetTrainer:
                                 ada=ada_v, ada_stride=ada_total)
         if self.dropout > 0.0:                   # dropout fused into the apply pass; the backward rebuilds the mask
             self._drop_calls += 1
-            sv.seed = (self.seed << 32) ^ (self.step_count << 12) ^ self._drop_calls
+            # one mask per (optimizer step, micro-batch, layer): accumulated micro-batches draw independently
+            sv.seed = (self.seed << 32) ^ (self.step_count << 16) ^ (self._micro_index << 10) ^ self._drop_calls
         sv.h1 = ops.gn_apply(sv.h, sv.c1, act=True, drop_seed=sv.seed or 0, drop_p=self.dropout if sv.seed is not None else 0.0)
         cm = 32 if x.dtype == torch.bfloat16 else 16
         if (b.skip_conv and self.FUSE_SKIP and ops.fused_conv_ok(b.res_out, b.res_out, b.out_channels)
@@ -560,6 +562,7 @@ class UNetTrainer:
         all-reduce is started as soon as the backward has written the bucket (data-parallel runs only)."""
         import torch.distributed as dist
         self._drop_calls = 0
+        self._micro_index = self.micro_batches if accumulate else 0      # position inside the optimizer step
         self._accumulating = bool(accumulate) and self.micro_batches > 0
         multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
         self._overlap = bool(last) and (multi or self._reduce_fn is not None)

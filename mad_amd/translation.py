@@ -80,7 +80,9 @@ class TranslationDiffusion:
             from PIL import Image
             image = Image.fromarray(image)
         if not isinstance(image, torch.Tensor):
-            image = image.resize((self.image_size, self.image_size))
+            # T.Resize's default interpolation is bilinear (translation.py:193-198); PIL's default is bicubic
+            from PIL import Image
+            image = image.resize((self.image_size, self.image_size), Image.BILINEAR)
             arr = np.asarray(image, dtype=np.float32) / 255.0
             image = torch.from_numpy(arr).permute(2, 0, 1)
             image = (image - 0.5) / 0.5
@@ -169,8 +171,9 @@ class TranslationDiffusion:
             if return_noise:
                 noises.append(model_output)
             self.scheduler.config.prediction_type = "epsilon"
-            latents[i + 1] = self.scheduler.compute_eps(model_output, timestep, noise_output, noise_output_next,
-                                                        eta=self.eta)
+            # the kernel writes the recovered noise straight into its slice of the step-major slab
+            self.scheduler.compute_eps(model_output, timestep, noise_output, noise_output_next, eta=self.eta,
+                                       out=latents[i + 1])
             noise_output = noise_output_next
         latents = latents.permute(1, 0, 2, 3, 4)             # (B, S, 3, H, W) view, step-major storage
         if return_noise:

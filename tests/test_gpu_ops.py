@@ -453,60 +453,3 @@ def test_conv3x3_img8(dev, case, dt):
     y2 = ops.conv2d(hin_n, w.permute(0, 2, 3, 1).contiguous().to(dt).to(dev), bias.to(dev),
                     residual=None if r is None else _nhwc(r, dt, dev), res_mode=mode)
     assert rel_err(y.float(), y2.float()) < (2e-5 if dt == torch.float32 else 6e-3)
-
-
-V2_CASES = [
-    # B, H, C1, C2, Cout, fuse, up, res, stats
-    (2, 64, 128, 0, 128, True, False, "none", True),      # one tile per workgroup: prologue + drain only
-    (4, 128, 128, 0, 256, True, False, "same", True),     # 512 tiles: two per workgroup, two n tiles, residual
-    (3, 128, 64, 64, 128, True, False, "none", True),     # concat of two sources, 192 tiles (ragged stream)
-    (2, 128, 128, 0, 128, True, True, "up", True),        # nearest x2 in the loader and on the residual
-    (5, 64, 256, 0, 128, False, False, "same", False),    # plain input, 8 chunks, no statistics
-    (9, 64, 160, 0, 128, True, False, "same", True),      # 5 chunks: store tail not a multiple of the chunk count
-]
-
-
-@pytest.mark.parametrize("case", V2_CASES)
-def test_conv3x3_role_split_kernel(dev, case, monkeypatch):
-    """The 8-wave persistent (role-split) form against an fp64 reference and against the 4-wave kernel."""
-    from mad_amd import _lib, ops
-    dt = torch.bfloat16
-    B, H, C1, C2, Cout, fuse, up, res, want_stats = case
-    C = C1 + C2
-    Hs = H // 2 if up else H
-    x1 = _rand((B, C1, Hs, Hs), 1, 1.3) + 0.2
-    x2 = _rand((B, C2, Hs, Hs), 2) if C2 else None
-    w = _rand((Cout, C, 3, 3), 3, 1.0 / math.sqrt(C * 9))
-    bias = _rand((Cout,), 4)
-    coef = torch.stack([1 + 0.3 * _rand((B, C), 5), 0.3 * _rand((B, C), 6)], dim=-1) if fuse else None
-    rshape = {"none": None, "same": (B, Cout, H, H), "up": (B, Cout, H // 2, H // 2)}[res]
-    r = _rand(rshape, 7) if rshape else None
-    mode = {"none": _lib.RES_NONE, "same": _lib.RES_SAME, "up": _lib.RES_UP}[res]
-    args = dict(coef=None if coef is None else coef.to(dev), act=True, x2=None if x2 is None else _nhwc(x2, dt, dev),
-                residual=None if r is None else _nhwc(r, dt, dev), res_mode=mode, upsample=up, want_stats=want_stats)
-    xin, wd, bd = _nhwc(x1, dt, dev), w.permute(0, 2, 3, 1).contiguous().to(dt).to(dev), bias.to(dev)
-    monkeypatch.setenv("MAD_HALO_V2", "0")
-    ref = ops.conv3x3_fused(xin, wd, bd, **args)
-    monkeypatch.setenv("MAD_HALO_V2", "1")
-    monkeypatch.setenv("MAD_HALO_V2_MIN_TILES", "1")
-    got = ops.conv3x3_fused(xin, wd, bd, **args)
-    torch.cuda.synchronize()
-    y_ref, y = (ref[0], got[0]) if want_stats else (ref, got)
-    # Same products and fp32 sums.  The residual is added to the bf16-rounded conv result (as a bf16
-    # tensor pipeline does), so next to the final rounding there is one of the intermediate t = y - res:
-    # the two kernels agree to one bf16 ulp of max(|y|, |t|).
-    diff = (y.float() - y_ref.float()).abs()
-    scale = y_ref.float().abs()
-    if r is not None:
-        rr = _nhwc(r, dt, dev).float()
-        if res == "up":
-            rr = rr.repeat_interleave(2, 1).repeat_interleave(2, 2)
-        scale = torch.maximum(scale, (y_ref.float() - rr).abs())
-    assert float((diff / scale.clamp_min(1.0)).max()) <= 2.0 ** -7, float((diff / scale.clamp_min(1.0)).max())
-    assert float((diff > 0).float().mean()) < (0.5 if res != "none" else 1e-3)
-    if want_stats:
-        yf = y.float()
-        s = got[1].sum(1).cpu()
-        assert rel_err(s[..., 0], yf.sum((1, 2)).cpu()) < 1e-4
-        assert rel_err(s[..., 1], (yf * yf).sum((1, 2)).cpu()) < 1e-4
-        assert tuple(got[1].shape) == tuple(ref[1].shape)

@@ -181,3 +181,34 @@ def test_library_import_brings_torch_runtime_first():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and out.stdout.strip() == "ok", out.stderr[-2000:]
+
+
+def test_shipped_configs_carry_the_reference_training_values():
+    """Values of the reference's configs/base.yaml, model_256_256.yaml and model_64_64.yaml that the
+    trimmed copies here once dropped (same-named config, same schedule)."""
+    from mad_amd.config import load_cfg
+    for name, batch, accum in (("model_256_256.yaml", 4, 8), ("model_64_64.yaml", 16, 4)):
+        cfg = load_cfg(os.path.join(REPO, "configs", name))
+        assert cfg.TRAIN.MAX_ITER == 700000
+        assert list(cfg.TRAIN.ROOT) == ["data/mtdataset/images"]
+        assert cfg.TRAIN.TEXT_LABEL_PATH == "data/mt_text_anno.json"
+        assert (cfg.TRAIN.BATCH_SIZE, cfg.TRAIN.GRADIENT_ACCUMULATION_STEPS) == (batch, accum)
+        assert cfg.TRAIN.MIXED_PRECISION == "fp16" and cfg.MODEL.LABEL_DIM == 2
+
+
+def test_process_image_resizes_bilinear():
+    """A PIL input that is not at IMAGE_SIZE is resized with the bilinear filter (torchvision's Resize default),
+    then scaled to [-1, 1] (reference translation.py:193-211)."""
+    import numpy as np
+    from PIL import Image
+    from mad_amd.translation import TranslationDiffusion
+    rng = np.random.default_rng(0)
+    img = Image.fromarray(rng.integers(0, 256, (40, 40, 3), dtype=np.uint8))
+    td = TranslationDiffusion.__new__(TranslationDiffusion)
+    td.image_size, td.device = 16, torch.device("cpu")
+    got = td.process_image(img)
+    want = np.asarray(img.resize((16, 16), Image.BILINEAR), dtype=np.float32) / 255.0
+    want = (torch.from_numpy(want).permute(2, 0, 1) - 0.5) / 0.5
+    assert tuple(got.shape) == (1, 3, 16, 16) and torch.equal(got[0], want)
+    bicubic = np.asarray(img.resize((16, 16)), dtype=np.float32)
+    assert not np.array_equal(bicubic, np.asarray(img.resize((16, 16), Image.BILINEAR), dtype=np.float32))

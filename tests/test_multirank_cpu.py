@@ -65,3 +65,32 @@ def _grad_worker(rank, world, port):
 @pytest.mark.timeout(120)
 def test_two_ranks_sum_the_flat_gradient():
     mp.spawn(_grad_worker, args=(2, _free_port()), nprocs=2, join=True)
+
+
+# ---- the self-launch path of the benchmarks: `python script.py --gpus N` as ONE plain process
+def test_relaunch_is_only_for_a_plain_process():
+    from mad_amd.launch import needs_relaunch, relaunch_command
+    assert needs_relaunch(2, environ={})
+    assert not needs_relaunch(1, environ={})
+    assert not needs_relaunch(2, environ={"RANK": "0", "WORLD_SIZE": "2"})        # already a rank
+    cmd = relaunch_command("bench.py", ["--gpus", "4", "--steps", "2"], 4, port=29999)
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-5:] == ["bench.py", "--gpus", "4", "--steps", "2"]
+
+
+@pytest.mark.timeout(300)
+def test_plain_process_starts_its_own_ranks():
+    import json
+    import subprocess
+    import sys
+    probe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "rank_probe.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, probe, "--gpus", "2"], env=env, capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    assert json.loads(lines[0]) == {"n_gpus": 2, "max": 2.0, "ranks_seen": 2}
+    # a rank that dies makes the launcher, and so the plain process, exit non-zero
+    r = subprocess.run([sys.executable, probe, "--gpus", "2", "--fail-rank", "1"], env=env, capture_output=True,
+                       text=True, timeout=280)
+    assert r.returncode != 0
