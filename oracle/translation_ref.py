@@ -110,8 +110,10 @@ class RefTranslation:
                  label_map: Optional[Tensor] = None, noise_initialize: Optional[Tensor] = None,
                  start_from_step: int = -1, comp_step: Optional[Dict[int, int]] = None,
                  extra_image: Optional[Tensor] = None, normalize: bool = True,
-                 trace: Optional[list] = None) -> Tensor:
-        """``label_map`` plays the role of ``source_mask_param`` with a pre-decoded label map."""
+                 trace: Optional[list] = None, source_after: Optional[list] = None) -> Tensor:
+        """``label_map`` plays the role of ``source_mask_param`` with a pre-decoded label map.  The reference
+        edits ``source_image`` in place when components switch on (translation.py:820-821); here a copy is
+        edited and, when ``source_after`` is a list, appended to it at the end."""
         if eps_list is not None:
             assert eps_list.shape[1] == (self.sample_steps if start_from_step == -1 else start_from_step)
             if noise_initialize is None:
@@ -158,5 +160,7 @@ class RefTranslation:
                     x = self.scheduler.step(out, t, x, eta=1.0 if t > 0 else 0,
                                             variance_noise=self.randn(x.shape),
                                             original_image=source_image, mask=source_mask).prev_sample
+        if source_after is not None:
+            source_after.append(source_image)
         x = x.clamp(-1, 1)
         return x / 2 + 0.5 if normalize else x

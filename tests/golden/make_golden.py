@@ -464,6 +464,112 @@ def refine_and_inversion_goldens():
     np.savez_compressed(os.path.join(HERE, "trajectory_refine.npz"), **out)
 
 
+def synthetic_label_map():
+    """The 64x64 face-parsing map of the mask fixtures (ellipses with the labels of BASIC_COMPONENT, hair as a
+    label outside it, eye pixels at the border for the reflect padding)."""
+    lab = np.zeros((64, 64), dtype=np.int64)
+    yy, xx = np.mgrid[0:64, 0:64]
+
+    def ell(cy, cx, ry, rx):
+        return ((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2 <= 1
+
+    lab[ell(34, 32, 26, 20)] = 4
+    lab[ell(58, 32, 8, 12)] = 10
+    lab[ell(36, 32, 7, 4)] = 8
+    lab[ell(26, 22, 2, 5)] = 1
+    lab[ell(26, 42, 2, 5)] = 6
+    lab[ell(21, 22, 1.2, 6)] = 2
+    lab[ell(21, 42, 1.2, 6)] = 7
+    lab[ell(47, 32, 1.5, 7)] = 9
+    lab[ell(50, 32, 1.5, 6)] = 13
+    lab[ell(6, 32, 6, 22)] = 12
+    lab[0:3, 0:5] = 1
+    return lab
+
+
+def transfer_goldens():
+    """trajectory_transfer.npz: the makeup-transfer form of ``generate`` -- per-step component activation
+    (``comp_step``), the keep-mask rebuilt from ``source_mask_param`` whenever a component switches on, and the
+    activated source regions replaced by the guide image (translation.py:799-821) -- run by the reference's own
+    ``encode`` and ``generate`` with the arguments ``image_translation`` passes them (translation.py:576-621),
+    on a 64x64 label map with a small denoiser, every random draw recorded.  The guide image stands in for the
+    host-side morphing result.  Component steps are the defaults (translation.py:37-47) divided by ten."""
+    install_placeholders()
+    sys.path.insert(0, REF)
+    import modeling.model as ref_model
+    import modeling.scheduler as ref_sched
+    import modeling.translation as ref_trans
+    from mad_amd.config import load_cfg
+    from mad_amd.unet_spec import spec_from_cfg
+
+    torch.set_grad_enabled(False)
+    cfg = load_cfg(os.path.join(REPO, "configs", "model_tiny64.yaml"))
+    spec = spec_from_cfg(cfg)
+    net = Adapter(build_ref_unet(ref_model, spec, seed=2))
+    lab = synthetic_label_map().astype(np.uint8)
+    comp_setup = {1: (0.8, 10), 6: (0.8, 10), 9: (0.8, 8), 13: (0.8, 8), 10: (0.35, 18), 4: (0.4, 18),
+                  8: (0.4, 18), 2: (0.8, 8), 7: (0.8, 8)}
+    start = max(s for _, s in comp_setup.values())
+
+    def smooth(seed):
+        z = seeded_inputs((1, 3, 64, 64), seed)
+        z = torch.nn.functional.avg_pool2d(z, 9, stride=1, padding=4) * 4.0
+        return z.clamp(-0.9, 0.9)
+
+    source, guide = smooth(51), smooth(52)
+    out = {"label_map": lab, "source": source.numpy(), "guide": guide.numpy(), "seed": np.int64(2),
+           "start": np.int64(start), "comp": np.array([[c, s] for c, (_, s) in comp_setup.items()], dtype=np.int64),
+           "comp_scale": np.array([w for (w, _) in comp_setup.values()], dtype=np.float32)}
+
+    td = ref_trans.TranslationDiffusion.__new__(ref_trans.TranslationDiffusion)
+    td.device, td.num_classes, td.sample_steps = "cpu", 2, 1000
+    td.refine_iterations, td.refine_steps, td.eta, td.null_text = 0, 0, 0.01, None
+    td.scheduler = ref_sched.CustomDDPMScheduler(num_train_timesteps=1000, prediction_type="epsilon",
+                                                 beta_schedule="linear", beta_start=1e-4, beta_end=0.02)
+    src, tgt = td.process_label(1, 1), td.process_label(0, 1)        # transfer: makeup -> non-makeup label order
+
+    def recorded(fn):
+        draws = []
+        real_randn, real_randn_like = torch.randn, torch.randn_like
+
+        def rec_randn(*a, **k):
+            z = real_randn(*a, **k)
+            draws.append(z.clone())
+            return z
+
+        def rec_randn_like(x, **k):
+            z = real_randn_like(x, **k)
+            draws.append(z.clone())
+            return z
+
+        torch.randn, torch.randn_like = rec_randn, rec_randn_like
+        try:
+            res = fn()
+        finally:
+            torch.randn, torch.randn_like = real_randn, real_randn_like
+        return res, draws
+
+    torch.manual_seed(2024)
+    eps_list, d_enc = recorded(lambda: td.encode(source, src, net, start_from_step=start))
+    out["enc_draws"] = torch.stack(d_enc).numpy()
+    out["eps_list"] = eps_list.numpy()
+    for tag, use_cam, inpainting in (("cam_inpaint", True, True), ("nocam_inpaint", False, True),
+                                     ("cam_noinpaint", True, False)):
+        param = {"mask": lab.copy(), "size": (64, 64), "landmarks": None}
+        comp_step = {c: (s if use_cam else ref_trans.MAX_STEP) for c, (_, s) in comp_setup.items()}
+        src_img = source.clone()
+        res, d = recorded(lambda: td.generate(net, eps_list=eps_list, class_label=tgt, source_image=src_img,
+                                              source_mask_param=param if inpainting else None,
+                                              noise_initialize=guide, start_from_step=start, comp_step=comp_step,
+                                              extra_image=guide))
+        out[f"{tag}/draws"] = torch.stack(d).numpy()
+        out[f"{tag}/out"] = res.numpy()
+        out[f"{tag}/source_after"] = src_img.numpy()       # the reference edits source_image in place
+        print(f"transfer {tag}: {len(d)} draws, |out - source| {float((res * 2 - 1 - source).abs().mean()):.4f}, "
+              f"source pixels replaced {float((src_img != source).float().mean()):.3f}")
+    np.savez_compressed(os.path.join(HERE, "trajectory_transfer.npz"), **out)
+
+
 def param_order_golden():
     """param_order.json: ``named_parameters()`` order of the reference module per config.  The
     reference restores EMA weights BY POSITION (``copy_parameters(shadow_params, model.parameters())``,
@@ -488,7 +594,10 @@ if __name__ == "__main__":
         refine_and_inversion_goldens()
     elif len(sys.argv) > 1 and sys.argv[1] == "params":
         param_order_golden()
+    elif len(sys.argv) > 1 and sys.argv[1] == "transfer":
+        transfer_goldens()
     else:
         main()
         refine_and_inversion_goldens()
+        transfer_goldens()
         param_order_golden()

@@ -118,6 +118,40 @@ def test_trajectory_matches_reference(dev, kind):
     assert float((out - torch.from_numpy(g[f"{kind}/out_target_masked"])).abs().max()) < 5e-4
 
 
+@pytest.mark.parametrize("kind", ["ddpm", "ddim"])
+def test_trajectory_bf16_end_image_psnr(dev, kind):
+    """The whole loop in bf16 mode against the reference's fp32 run on the same draws: noise encoding
+    followed by regeneration, 24 chained DDPM steps / 50 chained DDIM steps each way.  Gate: final images at
+    PSNR >= 40 dB (images in [0, 1], peak 1).  The sensitive quantity is the encoded noise -- compute_eps
+    divides the denoiser's error by sigma_t (reference scheduler.py:448-493, :147-197) -- so its per-step
+    error is bounded too: relative to the step's noise magnitude, <= 0.15 at every step and <= 0.05 in the mean."""
+    from mad_amd.translation import TranslationDiffusion
+    g = load_golden("trajectory.npz")
+    steps, start = int(g[f"{kind}/sample_steps"]), int(g[f"{kind}/start"])
+    cfg, m = _model("model_tiny.yaml", "bf16", 1, dev)
+    cfg.EVAL.SCHEDULER, cfg.EVAL.SAMPLE_STEPS, cfg.EVAL.ETA = kind, steps, 0.01
+    td = TranslationDiffusion(cfg, dev)
+    draws = iter(torch.from_numpy(np.concatenate([g[f"{kind}/enc_draws"], g[f"{kind}/gen_draws"]])))
+    td.noise_source = lambda shape: next(draws)
+    image = torch.from_numpy(g[f"{kind}/image"]).to(dev)
+    src, tgt = td.process_label(0, 2), td.process_label(1, 2)
+    eps_list = td.encode(image, src, m, start_from_step=start)
+    ref_eps = torch.from_numpy(g[f"{kind}/eps_list"])
+    errs = [rel_err(eps_list[:, i].cpu(), ref_eps[:, i]) for i in range(1, ref_eps.shape[1])]
+    print(f"{kind} bf16: encoded-noise relative error per step: max {max(errs):.3e}, mean {np.mean(errs):.3e}")
+    assert max(errs) <= 0.15 and float(np.mean(errs)) <= 0.05
+    assert torch.equal(eps_list[:, 0].cpu(), ref_eps[:, 0])        # x_T: one add_noise of the same draw, fp32
+    # regeneration from this run's own bf16-encoded noise (the product's pipeline end to end)
+    out = td.generate(m, eps_list=eps_list, class_label=src, source_image=image.clone(), start_from_step=start)
+    p_same = psnr(out, torch.from_numpy(g[f"{kind}/out_same_label"]), peak=1.0)
+    mask = torch.from_numpy(g[f"{kind}/mask"]).to(dev)
+    out = td.generate(m, eps_list=eps_list, class_label=tgt, source_image=image.clone(), source_mask=mask,
+                      start_from_step=start)
+    p_tgt = psnr(out, torch.from_numpy(g[f"{kind}/out_target_masked"]), peak=1.0)
+    print(f"{kind} bf16: final image PSNR {p_same:.1f} dB (same label), {p_tgt:.1f} dB (target label, masked)")
+    assert p_same >= 40.0 and p_tgt >= 40.0
+
+
 @pytest.mark.parametrize("kind,steps,start", [("ddpm", 1000, 12), ("ddim", 50, -1)])
 def test_replay_invariant(dev, kind, steps, start):
     """With the label unchanged, generate(eps_list=encode(...)) retraces the encoded trajectory: the
@@ -169,6 +203,61 @@ def test_transfer_loop_runs_with_component_masks(dev):
     assert float(out.min()) >= 0.0 and float(out.max()) <= 1.0 and torch.isfinite(out).all()
     with pytest.raises(NotImplementedError):
         td.image_translation(m, m, src, src, 0, 1)
+
+
+TRANSFER_CASES = [("cam_inpaint", True, True), ("nocam_inpaint", False, True), ("cam_noinpaint", True, False)]
+
+
+def _transfer_setup(g, dev, precision="fp32"):
+    from mad_amd.translation import COMP_INFO, TranslationDiffusion
+    cfg, m = _model("model_tiny64.yaml", precision, int(g["seed"]), dev)
+    cfg.EVAL.SCHEDULER, cfg.EVAL.SAMPLE_STEPS, cfg.EVAL.ETA = "ddpm", 1000, 0.01
+    td = TranslationDiffusion(cfg, dev)
+    setup = {int(c): COMP_INFO(float(w), int(s)) for (c, s), w in zip(g["comp"], g["comp_scale"])}
+    return cfg, m, td, setup
+
+
+@pytest.mark.parametrize("tag,use_cam,inpainting", TRANSFER_CASES)
+def test_transfer_generate_matches_reference(dev, tag, use_cam, inpainting):
+    """generate() as image_translation calls it (reference translation.py:608-621, loop :799-840): component
+    steps switch the keep-mask on the way, activated source regions are replaced by the guide image.  The
+    reference's encoded noise and draws are replayed; fp32 mode."""
+    from mad_amd.translation import MAX_STEP
+    g = load_golden("trajectory_transfer.npz")
+    cfg, m, td, setup = _transfer_setup(g, dev)
+    draws = iter(torch.from_numpy(g[f"{tag}/draws"]))
+    td.noise_source = lambda shape: next(draws)
+    source, guide = torch.from_numpy(g["source"]).to(dev), torch.from_numpy(g["guide"]).to(dev)
+    lab = torch.from_numpy(g["label_map"]).to(torch.uint8)
+    param = {"mask": lab, "size": (64, 64), "landmarks": None}
+    src_img = source.clone()
+    out = td.generate(m, eps_list=torch.from_numpy(g["eps_list"]).to(dev), class_label=td.process_label(0, 1),
+                      source_image=src_img, source_mask_param=param if inpainting else None,
+                      noise_initialize=guide, start_from_step=int(g["start"]),
+                      comp_step={c: (ci.step if use_cam else MAX_STEP) for c, ci in setup.items()}, extra_image=guide)
+    assert next(draws, None) is None
+    assert torch.equal(src_img.cpu(), torch.from_numpy(g[f"{tag}/source_after"]))     # in-place edit, as the reference
+    err = float((out - torch.from_numpy(g[f"{tag}/out"])).abs().max())
+    print(f"transfer generate {tag}: max abs err {err:.2e}")
+    assert err < 5e-4
+
+
+@pytest.mark.parametrize("tag,use_cam,inpainting", TRANSFER_CASES[:2])
+def test_image_translation_matches_reference(dev, tag, use_cam, inpainting):
+    """image_translation end to end (noise encoding of the source, then the guided regeneration) against the
+    reference's encode + generate on the same draws.  The encoded noise is this build's own here, so its
+    per-step error (compute_eps divides by sigma_t) reaches the image: 2e-3 absolute on [0, 1]."""
+    g = load_golden("trajectory_transfer.npz")
+    cfg, m, td, setup = _transfer_setup(g, dev)
+    draws = iter(torch.from_numpy(np.concatenate([g["enc_draws"], g[f"{tag}/draws"]])))
+    td.noise_source = lambda shape: next(draws)
+    source, guide = torch.from_numpy(g["source"]).to(dev), torch.from_numpy(g["guide"]).to(dev)
+    out = td.image_translation(m, m, source, source, 1, 0, source_parsing_mask=torch.from_numpy(g["label_map"]).to(torch.uint8),
+                               use_cam=use_cam, inpainting=inpainting, inverse_image=guide, comp_weight_step=setup)
+    assert next(draws, None) is None
+    err = float((out - torch.from_numpy(g[f"{tag}/out"])).abs().max())
+    print(f"image_translation {tag}: max abs err {err:.2e}")
+    assert err < 2e-3
 
 
 def test_refine_loop_matches_reference(dev):
@@ -232,6 +321,66 @@ def test_full_size_batch_consistency(dev, precision, tol):
     for i in (0, 13, 31):
         yi = m(x[i:i + 1].contiguous(), t, class_labels=lab[i:i + 1].contiguous())
         assert rel_err(y[i:i + 1].cpu(), yi.cpu()) < tol, i
+
+
+@pytest.mark.parametrize("precision,tol", [("fp32", 1e-4), ("bf16", 3e-2)])
+def test_full_size_batch_consistency_64(dev, precision, tol):
+    """The 64x64 model at its bench batch of 64 (channels 192/384/576/768, three blocks per level): the batch
+    selects launches a single image never sees -- the wide + narrow output-channel split of the halo kernel at
+    odd multiples of 64 channels, and the large-batch path of the 8x8 layers.  Each image must come out as it
+    does alone, and a repeat must be bit-identical."""
+    cfg, m = _model("model_64_64.yaml", precision, 1, dev)
+    g = torch.Generator(device="cpu").manual_seed(12)
+    x = torch.randn(64, 3, 64, 64, generator=g).to(dev)
+    lab = torch.eye(2, device=dev)[torch.arange(64, device=dev) % 2]
+    t = torch.tensor([271.0], device=dev)
+    y = m(x, t, class_labels=lab)
+    assert torch.isfinite(y).all()
+    assert torch.equal(y, m(x, t, class_labels=lab))
+    for i in (0, 29, 63):
+        yi = m(x[i:i + 1].contiguous(), t, class_labels=lab[i:i + 1].contiguous())
+        assert rel_err(y[i:i + 1].cpu(), yi.cpu()) < tol, i
+
+
+def test_full_size_transfer_with_component_masks(dev):
+    """Makeup transfer at full size (256x256 model, batch 32, bf16) with inpainting and per-step component
+    activation on per-image parsing maps, on a short component schedule: the result is finite and in [0, 1],
+    keep-regions come from the (guide-replaced) source, and an image translated alone with the same draws
+    equals its row of the batch to bf16 tolerance (every op on the path is per-sample)."""
+    from mad_amd.synthetic import synthetic_faces, synthetic_parsing_map
+    from mad_amd.translation import TranslationDiffusion
+    cfg, m = _model("model_256_256.yaml", "bf16", 1, dev)
+    B, R = 32, 256
+    src = synthetic_faces(B, R, seed=5).to(dev)
+    guide = synthetic_faces(B, R, seed=6).to(dev)
+    maps = torch.stack([synthetic_parsing_map(R, seed=i) for i in range(B)]).to(dev)
+    setup = {1: (0.8, 4), 6: (0.8, 4), 9: (0.8, 3), 13: (0.8, 3), 10: (0.35, 6), 4: (0.4, 6), 8: (0.4, 6),
+             2: (0.8, 3), 7: (0.8, 3)}
+    pool = torch.randn(16, B, 3, R, R, generator=torch.Generator().manual_seed(9)).to(dev)
+
+    def run(rows):
+        td = TranslationDiffusion(cfg, dev)
+        k = iter(range(pool.shape[0]))
+        td.noise_source = lambda shape: pool[next(k)][rows]
+        return td.image_translation(m, m, src[rows].contiguous(), src[rows].contiguous(), 1, 0,
+                                    source_parsing_mask=maps[rows].contiguous(), use_cam=True, inpainting=True,
+                                    inverse_image=guide[rows].contiguous(), comp_weight_step=setup)
+
+    out = run(slice(0, B))
+    assert tuple(out.shape) == (B, 3, R, R) and not out.is_cuda
+    assert torch.isfinite(out).all() and float(out.min()) >= 0.0 and float(out.max()) <= 1.0
+    for i in (3, 17):
+        one = run(slice(i, i + 1))
+        err = float((one - out[i:i + 1]).abs().max())
+        print(f"transfer full size: image {i} alone vs in the batch: max abs diff {err:.2e}")
+        assert err < 3e-2
+    # the final step (t = 0) writes sqrt(abar_prev) * source + 0 into the keep regions: with abar_prev = 1 there
+    # they equal the source as edited by the loop (guide pixels where the last mask keeps)
+    td = TranslationDiffusion(cfg, dev)
+    keep = td.process_mask(maps, (R, R)).cpu()                               # all components active at the end
+    want = (guide.cpu().clamp(-1, 1) / 2 + 0.5)
+    sel = (keep > 0).expand(-1, 3, -1, -1)
+    assert float((out[sel] - want[sel]).abs().max()) < 1e-6
 
 
 def test_graph_replay_matches_eager(dev):

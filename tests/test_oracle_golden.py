@@ -196,3 +196,41 @@ def test_inversion_start_matches_reference():
                       source_image=image, source_mask=mask, noise_initialize=ref_latent,
                       start_from_step=int(g["inversion/both/start"]))
     assert float((out - torch.from_numpy(g["inversion/both/out"])).abs().max()) < 2e-4
+
+
+TRANSFER_CASES = [("cam_inpaint", True, True), ("nocam_inpaint", False, True), ("cam_noinpaint", True, False)]
+
+
+@pytest.mark.parametrize("tag,use_cam,inpainting", TRANSFER_CASES)
+def test_transfer_loop_matches_reference(tag, use_cam, inpainting):
+    """The makeup-transfer form of generate() (translation.py:799-821 with the arguments of :608-621): per-step
+    component activation, keep-mask rebuilt from the label map, activated source regions replaced by the guide."""
+    from oracle.translation_ref import MAX_STEP
+    g = load_golden("trajectory_transfer.npz")
+    spec, sd, kw = _oracle_unet("model_tiny64.yaml", int(g["seed"]))
+    model = lambda x, t, labels: unet_forward(sd, x, t, labels, **kw)
+    source, guide = torch.from_numpy(g["source"]), torch.from_numpy(g["guide"])
+    lab, start = torch.from_numpy(g["label_map"]).long(), int(g["start"])
+    comp_step = {int(c): (int(s) if use_cam else MAX_STEP) for c, s in g["comp"]}
+    draws = iter(torch.from_numpy(g[f"{tag}/draws"]))
+    tr = RefTranslation(RefScheduler("ddpm"), 2, sample_steps=1000, eta=0.01, randn=lambda shape: next(draws))
+    after = []
+    out = tr.generate(model, eps_list=torch.from_numpy(g["eps_list"]), class_label=tr.process_label(0, 1),
+                      source_image=source, label_map=lab if inpainting else None, noise_initialize=guide,
+                      start_from_step=start, comp_step=comp_step, extra_image=guide, source_after=after)
+    assert next(draws, None) is None
+    np.testing.assert_array_equal(after[0].numpy(), g[f"{tag}/source_after"])
+    assert float((out - torch.from_numpy(g[f"{tag}/out"])).abs().max()) < 2e-4
+
+
+def test_transfer_encode_matches_reference():
+    g = load_golden("trajectory_transfer.npz")
+    spec, sd, kw = _oracle_unet("model_tiny64.yaml", int(g["seed"]))
+    model = lambda x, t, labels: unet_forward(sd, x, t, labels, **kw)
+    draws = iter(torch.from_numpy(g["enc_draws"]))
+    tr = RefTranslation(RefScheduler("ddpm"), 2, sample_steps=1000, eta=0.01, randn=lambda shape: next(draws))
+    eps = tr.encode(torch.from_numpy(g["source"]), tr.process_label(1, 1), model, start_from_step=int(g["start"]))
+    ref = torch.from_numpy(g["eps_list"])
+    assert eps.shape == ref.shape
+    for i in range(eps.shape[1]):
+        assert rel_err(eps[:, i], ref[:, i]) < 5e-3, i
