@@ -205,6 +205,21 @@ int mad_gn_finalize(const float* partial1, int C1, int nsplit1, const float* par
                     int nsplit2, const float* gamma, const float* beta, const float* ada,
                     int ada_stride, float* coef, int B, int groups, int HW, float eps, void* stream);
 
+/* GroupNorm coefficients in ONE call that allocates nothing: mad_gn_partial followed by mad_gn_finalize with
+ * the partial-sum slab between them held in a device array inside the library (8 MiB per GPU, kept until the
+ * process ends) instead of a caller-owned buffer.  No counterpart in the reference: it exists for callers
+ * that cannot allocate device memory between the two passes -- code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc.  x is the concatenation of x1 (C1) and x2 (C2, may be NULL/0), NHWC
+ * with HW pixels per image; the split count is min(64, max(1, HW/64)) as the two-call form uses, and
+ * B * splits * (C1+C2) * 2 floats must fit mad_gn_coef_static_max_floats() (rejected with a message otherwise).
+ * Result coef fp32 (B, C1+C2, 2), bit-identical to the two-call form.  The first call on a device looks the
+ * slab's address up (do it once outside graph capture).  Calls on one GPU share that GPU's slab: two calls
+ * that overlap in time on different streams race; calls on one stream are ordered. */
+size_t mad_gn_coef_static_max_floats(void);
+int mad_gn_coef_static(const void* x1, int C1, const void* x2, int C2, int dtype, const float* gamma,
+                       const float* beta, const float* ada, int ada_stride, float* coef, int B, int HW,
+                       int groups, float eps, void* stream);
+
 /* y = act(x*a + d) over the concatenation of x1/x2, written as one (B,H,W,C1+C2) tensor
  * (or (B,H/2,W/2,C) with the 2x2 mean of the activated values when `pool` is set: the `down`
  * resample of model.py:155-161 applied after norm+SiLU).  act: 0 none, 1 SiLU. */

@@ -85,6 +85,9 @@ SIGNATURES = {
     "mad_gn_partial": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
     "mad_gn_finalize": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int,
                                 c_void_p, c_int, c_int, c_int, c_float, c_void_p]),
+    "mad_gn_coef_static_max_floats": (ctypes.c_size_t, []),
+    "mad_gn_coef_static": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
+                                   c_int, c_int, c_int, c_float, c_void_p]),
     "mad_gn_apply": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
     "mad_attention": (c_int, [c_void_p, c_void_p] + [c_int] * 4 + [c_void_p]),
     "mad_attention_lse": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 4 + [c_void_p]),

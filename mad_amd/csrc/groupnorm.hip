@@ -4,6 +4,8 @@
 // All of it is HBM-bound: 16-byte vector accesses, wave-level reductions, fp32 statistics.
 #include "common.h"
 
+#include <mutex>
+
 namespace mad {
 
 // ------------------------------------------------------------------------------- partial sums
@@ -278,4 +280,60 @@ extern "C" int mad_gn_apply_dropout(const void* x1, int C1, const void* x2, int 
                                     void* stream) {
     MAD_REQUIRE(p >= 0.0f && p < 1.0f, "mad_gn_apply_dropout: p=%f out of [0,1)", (double)p);
     return gn_apply_impl(x1, C1, x2, C2, coef, y, dtype, B, H, W, act, 0, make_drop_mask(seed, p), stream);
+}
+
+// ------------------------------------------------------------------------------- no-allocation variant
+// mad_gn_partial + mad_gn_finalize in one call, for callers that cannot allocate the partial-sum slab between
+// the two passes.  The slab lives in a device array of this code object; every GPU the library runs on holds
+// its own copy at its own address, looked up once per device.  In host code the array's NAME is only a handle
+// for that lookup: kernels are given the looked-up pointer.
+namespace mad {
+
+constexpr size_t GN_STATIC_FLOATS = (size_t)1 << 21;                 // 8 MiB of partial sums per GPU
+static __device__ __align__(256) float scratch[GN_STATIC_FLOATS];
+
+constexpr int GN_STATIC_MAX_DEVICES = 64;
+static float* g_scratch_ptr[GN_STATIC_MAX_DEVICES];                  // per device; null until first use there
+static std::mutex g_scratch_mutex;
+
+// the current device's copy of `scratch` (0 = ok)
+static int gn_static_slab(float** out) {
+    int dev = -1;
+    MAD_REQUIRE(hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < GN_STATIC_MAX_DEVICES,
+                "mad_gn_coef_static: cannot identify the current device");
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[dev]) {
+        float* p = nullptr;
+        const hipError_t e = hipGetSymbolAddress((void**)&p, HIP_SYMBOL(scratch));
+        MAD_REQUIRE(e == hipSuccess && p, "mad_gn_coef_static: hipGetSymbolAddress failed on device %d: %s", dev,
+                    hipGetErrorString(e));
+        g_scratch_ptr[dev] = p;
+    }
+    *out = g_scratch_ptr[dev];
+    return 0;
+}
+
+}  // namespace mad
+
+extern "C" size_t mad_gn_coef_static_max_floats(void) { return mad::GN_STATIC_FLOATS; }
+
+extern "C" int mad_gn_coef_static(const void* x1, int C1, const void* x2, int C2, int dtype, const float* gamma,
+                                  const float* beta, const float* ada, int ada_stride, float* coef, int B, int HW,
+                                  int groups, float eps, void* stream) {
+    MAD_REQUIRE(x1 && gamma && beta && coef, "mad_gn_coef_static: null pointer");
+    MAD_REQUIRE(B > 0 && HW > 0 && C1 > 0 && C2 >= 0, "mad_gn_coef_static: bad shape");
+    int nsplit = HW / 64;                                             // the split count the two-call form uses
+    nsplit = nsplit < 1 ? 1 : (nsplit > 64 ? 64 : nsplit);
+    MAD_REQUIRE(HW % nsplit == 0, "mad_gn_coef_static: HW=%d is not a multiple of its %d splits", HW, nsplit);
+    const size_t need = (size_t)B * nsplit * (C1 + C2) * 2;
+    MAD_REQUIRE(need <= GN_STATIC_FLOATS,
+                "mad_gn_coef_static: B=%d x %d splits x %d channels needs %zu floats of partial sums, the static slab "
+                "holds %zu: use mad_gn_partial + mad_gn_finalize with a caller-owned slab",
+                B, nsplit, C1 + C2, need, (size_t)GN_STATIC_FLOATS);
+    float* slab = nullptr;
+    if (int rc = gn_static_slab(&slab)) return rc;
+    // every element the second pass reads is written by the first: nothing has to start at zero
+    if (int rc = mad_gn_partial(x1, C1, x2, C2, dtype, slab, B, HW, nsplit, stream)) return rc;
+    return mad_gn_finalize(slab, C1 + C2, nsplit, nullptr, 0, 0, gamma, beta, ada, ada_stride, coef, B, groups, HW, eps,
+                           stream);
 }

@@ -651,6 +651,23 @@ def gn_coef(x1: Tensor, gamma: Tensor, beta: Tensor, groups: int, eps: float, x2
     return gn_finalize(gn_partial(x1, x2), H * W_, gamma, beta, groups, eps, ada=ada, ada_stride=ada_stride)
 
 
+def gn_coef_static(x1: Tensor, gamma: Tensor, beta: Tensor, groups: int, eps: float, x2: Optional[Tensor] = None,
+                   ada: Optional[Tensor] = None, ada_stride: int = 0, out: Optional[Tensor] = None) -> Tensor:
+    """``gn_coef`` through the library's entry point that allocates nothing: the partial sums stay in a device
+    array inside the library.  With ``out`` given (fp32 (B, C, 2)) this wrapper allocates nothing either."""
+    _dev(x1, x2, gamma, beta, out)
+    B, H, W_, C1 = x1.shape
+    C2 = 0 if x2 is None else x2.shape[3]
+    if out is None:
+        out = torch.empty((B, C1 + C2, 2), dtype=torch.float32, device=x1.device)
+    elif out.dtype != torch.float32 or tuple(out.shape) != (B, C1 + C2, 2):
+        raise ValueError("gn_coef_static: out must be fp32 (B, C, 2)")
+    check(lib.mad_gn_coef_static(_ptr(x1), C1, _ptr(x2), C2, _dtype_code(x1), _ptr(gamma), _ptr(beta),
+                                 None if ada is None else ada.data_ptr(), ada_stride, _ptr(out), B, H * W_, groups,
+                                 float(eps), _stream()), "mad_gn_coef_static")
+    return out
+
+
 def gn_apply(x1: Tensor, coef: Tensor, act: bool, x2: Optional[Tensor] = None, pool: bool = False,
              drop_seed: int = 0, drop_p: float = 0.0) -> Tensor:
     """y = act(x*a + d) (optionally 2x2-averaged); with ``drop_p`` > 0 the result is dropped out in the same pass
