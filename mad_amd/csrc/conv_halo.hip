@@ -43,13 +43,19 @@ struct HaloArgs {
     DropMask gdm;
 };
 
-constexpr int HT = 16;                 // output tile edge
-constexpr int HS = 18;                 // halo edge
+constexpr int HT = 16;                 // output tile height (and width of the narrow tile)
+constexpr int HS = 18;                 // halo rows
 constexpr int HROW = 64;               // bytes per halo pixel / weight row per K-tile
-constexpr int HALO_ITEMS = HS * HS * 4;                 // 16-byte items per halo chunk: 1296
-constexpr int HALO_BUF = (HALO_ITEMS + 63) / 64 * 64 * 16;   // 21504: whole wave-instructions
+// Output tile = 16 rows x TW columns, TW = 16 (four waves) or 32 (eight waves: two 16x16 halves side by side that
+// share one stream of weight tiles -- half the weight copies per multiply -- and a 18 x 34 halo).
+template <int TW> constexpr int halo_items() { return HS * (TW + 2) * 4; }      // 16-byte items per halo chunk
+template <int TW> constexpr int halo_buf() { return (halo_items<TW>() + 63) / 64 * 64 * 16; }   // whole wave-instructions
 constexpr int CTAB_BYTES = 1024;       // one DMA instruction's worth; 256 (bf16) / 128 (fp32) bytes used
-constexpr int NWBUF = 3;
+#ifndef MAD_HALO_PF
+#define MAD_HALO_PF 2
+#endif
+constexpr int PF = MAD_HALO_PF;        // weight tiles are copied PF K-tiles ahead of their use
+constexpr int NWBUF = PF + 1;
 
 #ifdef MAD_HALO_STAMPS
 // Timing aid (separate build only): cycle stamps of every wave of one workgroup for the taps of its
@@ -71,8 +77,8 @@ __device__ unsigned g_stamps[8 * 9 * 8];
 #define MAD_STAMP_PHASE(k)
 #endif
 
-template <int BN> constexpr int halo_lds_bytes() {
-    constexpr int stage = 2 * HALO_BUF + NWBUF * BN * HROW + 2 * CTAB_BYTES + 1024;   // + one sink KiB
+template <int BN, int TW> constexpr int halo_lds_bytes() {
+    constexpr int stage = 2 * halo_buf<TW>() + NWBUF * BN * HROW + 2 * CTAB_BYTES + 1024;   // + one sink KiB
     constexpr int epi = 128 * (BN + 4) * 4;
 #ifdef MAD_HALO_STAMPS
     return (stage > epi ? stage : epi) + 4096;
@@ -82,14 +88,19 @@ template <int BN> constexpr int halo_lds_bytes() {
 }
 
 // OUT_NCHW: write the first a.Cout (<= BN) channels as NCHW fp32 with bias (last layer).
-template <typename T, bool FUSE, int WM, int WN, int TN, bool OUT_NCHW, bool SKIP, bool GSTAT>
-__global__ __launch_bounds__(64 * WM * WN, WM * WN / 2) void conv3x3_halo_kernel(HaloArgs a) {
+template <typename T, bool FUSE, int WM, int WN, int TN, bool OUT_NCHW, bool SKIP, bool GSTAT, int TW = 16>
+__global__ __launch_bounds__(64 * WM * WN, WM * WN / (TW / 16) / 2) void conv3x3_halo_kernel(HaloArgs a) {
     constexpr int NWAVES = WM * WN, NT = 64 * NWAVES;
     static_assert(NWAVES == 4 || NWAVES == 8, "4 or 8 waves");
-    constexpr int HALO_ROUNDS = (HALO_ITEMS + NT - 1) / NT;   // items per thread: 6 (4 waves) / 3 (8 waves)
+    static_assert(TW == 16 || TW == 32, "tile width");
+    constexpr int HSX = TW + 2;                    // halo columns
+    constexpr int HALO_ITEMS = halo_items<TW>(), HALO_BUF = halo_buf<TW>();
+    constexpr int HALO_ROUNDS = (HALO_ITEMS + NT - 1) / NT;   // items per thread: 6 (16 wide, 4 waves) / 5 (32 wide, 8 waves)
     static_assert(HALO_ROUNDS <= 6, "one halo item per tap, transformed three taps later");
     constexpr int BN = WN * TN * 32;
-    constexpr int TM = 8 / WM;                     // 32-pixel accumulator tiles per wave (2 tile rows each)
+    constexpr int WMH = WM / (TW / 16);            // waves stacked along the rows of one 16-column half
+    static_assert(WMH >= 2 && WM % (TW / 16) == 0, "a wave covers at most 8 rows of one half");
+    constexpr int TM = 8 / WMH;                    // 32-pixel accumulator tiles per wave (2 tile rows each)
     constexpr int WTILE_BYTES = BN * HROW;
     constexpr int EPI_LD = BN + 4;
     constexpr int VEC = Elem<T>::VEC;
@@ -113,13 +124,13 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / 2) void conv3x3_halo_kernel
     const int nt = logical % a.ntiles_n; logical /= a.ntiles_n;
     const int tile = logical % tiles_img;
     const int b = logical / tiles_img;
-    const int ty0 = (tile / a.tiles_x) * HT, tx0 = (tile % a.tiles_x) * HT;
+    const int ty0 = (tile / a.tiles_x) * HT, tx0 = (tile % a.tiles_x) * TW;
     const int n0 = a.n_off + nt * BN;
 
     const int Ctot = a.C1 + a.C2;
     const int nchunks = Ctot / CK;
 #ifdef MAD_HALO_STAMPS
-    unsigned* const stamp_lds = reinterpret_cast<unsigned*>(smem + halo_lds_bytes<BN>() - 4096);
+    unsigned* const stamp_lds = reinterpret_cast<unsigned*>(smem + halo_lds_bytes<BN, TW>() - 4096);
     const bool stamp_on = blockIdx.x == gridDim.x / 2 + 3;
     const int lane_ = threadIdx.x & 63, wave_ = threadIdx.x >> 6;
     if (stamp_on) {
@@ -134,17 +145,21 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / 2) void conv3x3_halo_kernel
     // area that nobody reads, so that every wave issues the same number of memory operations (the counted
     // waits below rely on it) and no copy can land on an item that was already transformed in place.
     const bool last_round_real = NT * (HALO_ROUNDS - 1) + 64 * wave < HALO_BUF / 16;
-    int src_pix[HALO_ROUNDS];        // source pixel index (b*Hs + sy)*Ws + sx, or -1: padding / no item
+    // source pixel index (b*Hs + sy)*Ws + sx of each item.  Padding / no item: -1 in the plain form (copied from the
+    // zero page); in the FUSE form 0 with the item's bit set in padmask (the transform writes zeros there)
+    int src_pix[HALO_ROUNDS];
+    unsigned padmask = 0;
     unsigned lchunks = 0;            // 2 bits per round: logical chunk of this thread's item
 #pragma unroll
     for (int j = 0; j < HALO_ROUNDS; ++j) {
         const int item = tid + NT * j;
         const int p = item >> 2;
-        const int hy = p / HS, hx = p - hy * HS;
+        const int hy = p / HSX, hx = p - hy * HSX;
         const int iy = ty0 - 1 + hy, ix = tx0 - 1 + hx;
         const bool ok = item < HALO_ITEMS && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
         const int sy = a.upsample ? iy >> 1 : iy, sx = a.upsample ? ix >> 1 : ix;
-        src_pix[j] = ok ? (b * a.Hs + sy) * a.Ws + sx : -1;
+        src_pix[j] = ok ? (b * a.Hs + sy) * a.Ws + sx : (FUSE ? 0 : -1);
+        if (!ok) padmask |= 1u << j;
         lchunks |= (unsigned)((tid & 3) ^ ((hx >> 1) & 3)) << (2 * j);
     }
     const unsigned halo_base = lds_addr(halo0);
@@ -155,18 +170,25 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / 2) void conv3x3_halo_kernel
         if (c0 < a.C1) { src = (const T*)a.x1; cs = a.C1; coff = c0; }
         else { src = (const T*)a.x2; cs = a.C2; coff = c0 - a.C1; }
         const int lc = (lchunks >> (2 * j)) & 3;
-        const T* p = src + (size_t)max(src_pix[j], 0) * cs + coff + lc * VEC;
-        const void* g = src_pix[j] >= 0 ? (const void*)p : (const void*)g_zero_page;
         const bool sink = j == HALO_ROUNDS - 1 && !last_round_real;     // wave-uniform
         const unsigned dst = sink ? sink_base : halo_base + buf * HALO_BUF + (NT * j + 64 * wave) * 16;
-        glds16(sink ? (const void*)g_zero_page : g, __builtin_amdgcn_readfirstlane(dst));
+        if constexpr (FUSE) {
+            // scalar base = the source's channel chunk, 32-bit lane offset = pixel and logical chunk (pixel index
+            // and row pitch both below 2^24; the tensor below 4 GB: checked on the host)
+            const unsigned off = (__umul24((unsigned)src_pix[j], (unsigned)cs) + lc * VEC) * (unsigned)sizeof(T);
+            glds16s(src + coff, off, __builtin_amdgcn_readfirstlane(dst));
+        } else {
+            const T* p = src + (size_t)max(src_pix[j], 0) * cs + coff + lc * VEC;
+            const void* g = src_pix[j] >= 0 ? (const void*)p : (const void*)g_zero_page;
+            glds16(sink ? (const void*)g_zero_page : g, __builtin_amdgcn_readfirstlane(dst));
+        }
     };
     // GroupNorm coefficient table of one chunk: CK channels x (a, d) fp32, same copy from every wave
     const unsigned ctab_base = lds_addr(ctab0);
     auto dma_coef = [&](int cc, int buf) {
         constexpr int LANES = CK * 8 / 16;          // 16 (bf16) / 8 (fp32) lanes carry the table
-        const float* g = a.coef + ((size_t)b * Ctot + cc * CK) * 2 + (lane & (LANES - 1)) * 4;
-        glds16(g, __builtin_amdgcn_readfirstlane(ctab_base + buf * CTAB_BYTES));
+        glds16s(a.coef + ((size_t)b * Ctot + cc * CK) * 2, (unsigned)(lane & (LANES - 1)) * 16u,
+                __builtin_amdgcn_readfirstlane(ctab_base + buf * CTAB_BYTES));
     };
     // in-place y = act(x*a + d) of this thread's item j in halo buffer `buf` (zeros for padding)
     auto xform_item = [&](int j, int buf) {
@@ -186,21 +208,80 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / 2) void conv3x3_halo_kernel
             f[i + 1] = a.act ? silu_f(t1) : t1;
         }
         v.pack(f);
-        if (src_pix[j] < 0) v.raw = make_uint4(0, 0, 0, 0);
+        if ((padmask >> j) & 1) v.raw = make_uint4(0, 0, 0, 0);
         *reinterpret_cast<uint4*>(addr) = v.raw;
+    };
+
+    // The same transform cut into 16 short pieces, one behind each MFMA of a tap (in-loop form): the matrix
+    // pipe runs the MFMA while the vector pipe runs the piece, instead of the whole transform standing behind
+    // the tap's last MFMA.  Element pair p (one dword of bf16, two floats of fp32) goes through four stages in
+    // the slots XSTRIDE*p .. XSTRIDE*p+3: unpack + multiply-add, exp, reciprocal + product, pack.  The item and
+    // the first coefficient pair are requested at the top of the tap; each later coefficient pair one pair ahead.
+    constexpr int XPAIRS = VEC / 2, XSTRIDE = 16 / XPAIRS;
+    uint4 xraw; float4 xcf[2]; float xt[2], xu[2]; unsigned xout[4];
+    const float xk1 = a.act ? -1.44269504088896340736f : 0.0f, xk0 = a.act ? 0.0f : -200.0f;
+    const unsigned char* xaddr = nullptr; const float* xcoef = nullptr;
+    auto xf_begin = [&](int j, int buf) {
+        const int item = tid + NT * j;
+        xaddr = halo0 + buf * HALO_BUF + item * 16;
+        xraw = *reinterpret_cast<const uint4*>(xaddr);
+        const int lc = (lchunks >> (2 * j)) & 3;
+        xcoef = reinterpret_cast<const float*>(ctab0 + buf * CTAB_BYTES) + lc * VEC * 2;
+        xcf[0] = *reinterpret_cast<const float4*>(xcoef);
+    };
+    auto xf_slot = [&](int s, int j) {
+        const int pr = s / XSTRIDE, k = s % XSTRIDE;
+        if (pr >= XPAIRS || k > 3) return;
+        if (k == 0) {
+            const unsigned* w = reinterpret_cast<const unsigned*>(&xraw);
+            float f0, f1;
+            if (sizeof(T) == 2) { f0 = __uint_as_float(w[pr] << 16); f1 = __uint_as_float(w[pr] & 0xffff0000u); }
+            else { f0 = __uint_as_float(w[2 * pr]); f1 = __uint_as_float(w[2 * pr + 1]); }
+            const float4 ad = xcf[pr & 1];
+            if (pr + 1 < XPAIRS) xcf[(pr + 1) & 1] = *reinterpret_cast<const float4*>(xcoef + 4 * (pr + 1));
+            xt[0] = fmaf(f0, ad.x, ad.y); xt[1] = fmaf(f1, ad.z, ad.w);
+            // exponent of the sigmoid: -t*log2(e) with the activation, -200 without it (exp2 gives 0, the
+            // reciprocal 1, the product t itself): no select on the way
+            xu[0] = fmaf(xt[0], xk1, xk0); xu[1] = fmaf(xt[1], xk1, xk0);
+        } else if (k == 1) {
+            xu[0] = 1.0f + __builtin_amdgcn_exp2f(xu[0]); xu[1] = 1.0f + __builtin_amdgcn_exp2f(xu[1]);
+        } else if (k == 2) {
+            xt[0] *= __builtin_amdgcn_rcpf(xu[0]); xt[1] *= __builtin_amdgcn_rcpf(xu[1]);
+        } else {
+            if (sizeof(T) == 2) {
+                typedef float f32x2_t __attribute__((ext_vector_type(2)));
+                typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+                const f32x2_t v2 = {xt[0], xt[1]};
+                xout[pr] = __builtin_bit_cast(unsigned, __builtin_convertvector(v2, bf16x2_t));
+            } else { xout[2 * pr] = __float_as_uint(xt[0]); xout[2 * pr + 1] = __float_as_uint(xt[1]); }
+            if (pr == XPAIRS - 1) {
+                const bool pad = (padmask >> j) & 1;
+                uint4 o = make_uint4(pad ? 0u : xout[0], pad ? 0u : xout[1], pad ? 0u : xout[2], pad ? 0u : xout[3]);
+                const int item = tid + NT * j;
+                if (j < HALO_ROUNDS - 1 || item < HALO_ITEMS)
+                    *reinterpret_cast<uint4*>(const_cast<unsigned char*>(xaddr)) = o;
+            }
+        }
     };
 
     // ---- weight tile DMA: one wave-instruction covers 16 rows of 64 bytes; every wave issues NW of them
     // (for BN < 64 some waves repeat another wave's copy)
     const unsigned wt_base = lds_addr(wt0);
+    unsigned wrow_off[NW];           // this lane's row and logical chunk inside the layer's weights, bytes
+#pragma unroll
+    for (int j = 0; j < NW; ++j) {
+        const int blk = (j * NWAVES + wave) % (BN / 16);   // 16-row block index
+        const int r = blk * 16 + (lane >> 2);
+        const int lchunk = (lane & 3) ^ ((r >> 2) & 3);
+        wrow_off[j] = (unsigned)((r * 9 * Ctot + lchunk * VEC) * (int)sizeof(T));
+    }
     auto stage_w = [&](int cc, int tap, int buf) {
+        // scalar base = first row of this workgroup's channels at (tap, chunk); the lane offset never changes
+        const T* base = (const T*)a.w + ((size_t)n0 * 9 + tap) * Ctot + cc * CK;
 #pragma unroll
         for (int j = 0; j < NW; ++j) {
-            const int blk = (j * NWAVES + wave) % (BN / 16);   // 16-row block index
-            const int r = blk * 16 + (lane >> 2);
-            const int lchunk = (lane & 3) ^ ((r >> 2) & 3);
-            const T* g = (const T*)a.w + ((size_t)(n0 + r) * 9 + tap) * Ctot + cc * CK + lchunk * VEC;
-            glds16(g, __builtin_amdgcn_readfirstlane(wt_base + buf * WTILE_BYTES + blk * 16 * HROW));
+            const int blk = (j * NWAVES + wave) % (BN / 16);
+            glds16s(base, wrow_off[j], __builtin_amdgcn_readfirstlane(wt_base + buf * WTILE_BYTES + blk * 16 * HROW));
         }
     };
 
@@ -209,8 +290,8 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / 2) void conv3x3_halo_kernel
     int a_off[3][2];     // [kx][kk]: byte offset of this lane's A chunk for this wave's first tile row
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx) {
-        const int hx = (fr & 15) + kx;
-        const int pix = (wm * (16 / WM) + (fr >> 4)) * HS + hx;
+        const int hx = (wm / WMH) * 16 + (fr & 15) + kx;
+        const int pix = ((wm % WMH) * (16 / WMH) + (fr >> 4)) * HSX + hx;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) a_off[kx][kk] = pix * HROW + (((2 * kk + fh) ^ ((hx >> 1) & 3)) << 4);
     }
@@ -234,15 +315,15 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / 2) void conv3x3_halo_kernel
     if (FUSE) dma_coef(0, 0);
 #pragma unroll
     for (int j = 0; j < HALO_ROUNDS; ++j) dma_item(0, j, 0);
-    stage_w(0, 0, 0);
-    stage_w(0, 1, 1);
+#pragma unroll
+    for (int t = 0; t < PF; ++t) stage_w(0, t, t);
     if (FUSE) {
         // Copies retire in issue order: item j is transformed as soon as it (and the table, which every
         // wave copies for itself) has landed, while the later items and the weight tiles are still in flight.
-        static_assert(HALO_ROUNDS - 1 + 2 * NW < 64, "vmcnt range");
+        static_assert(HALO_ROUNDS - 1 + PF * NW < 64, "vmcnt range");
 #pragma unroll
         for (int j = 0; j < HALO_ROUNDS; ++j) {
-            switch (HALO_ROUNDS - 1 - j + 2 * NW) {
+            switch (HALO_ROUNDS - 1 - j + PF * NW) {
                 case 0: dma_wait_upto<0>(); break;
                 case 1: dma_wait_upto<1>(); break;
                 case 2: dma_wait_upto<2>(); break;
@@ -253,6 +334,8 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / 2) void conv3x3_halo_kernel
                 case 7: dma_wait_upto<7>(); break;
                 case 8: dma_wait_upto<8>(); break;
                 case 9: dma_wait_upto<9>(); break;
+                case 10: dma_wait_upto<10>(); break;
+                case 11: dma_wait_upto<11>(); break;
                 default: dma_wait_all(); break;
             }
             xform_item(j, 0);
@@ -260,10 +343,11 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / 2) void conv3x3_halo_kernel
     }
     dma_wait_all();
 
-    // Operations a wave issues at tap t, in order: NW weight copies (K-tile t+2), the coefficient copy
-    // (t == 0, FUSE), one halo item (t < 6).  Weight tile t was issued first at tap t-2, so at the top of
-    // tap t everything but the operations issued after it may still be in flight:
-    //   N(t) = [coef(t-2) + item(t-2)] + NW + [coef(t-1) + item(t-1)]        (indices mod 9)
+    // Operations a wave issues at tap t, in order: the coefficient copy (t == 0, FUSE), one halo item (t < 6),
+    // then NW weight copies (K-tile t+PF).  Weight tile t was the last thing issued at tap t-PF, so at the top
+    // of tap t everything issued at the taps in between may still be in flight:
+    //   N(t) = sum over x = t-PF+1 .. t-1 of coef(x) + item(x) + NW          (indices mod 9)
+    // and a halo item issued at tap j has landed when the wait of tap j+PF is over.
     MAD_STAMP_PHASE(1)
     for (int cc = 0; cc < nchunks; ++cc) {
         const unsigned char* halo = halo0 + (cc & 1) * HALO_BUF;
@@ -273,9 +357,13 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / 2) void conv3x3_halo_kernel
         for (int tap = 0; tap < 9; ++tap) {
             const int ky = tap / 3, kx = tap % 3;
             constexpr int C0 = FUSE ? 1 : 0;
-            const int t1 = (tap + 8) % 9, t2 = (tap + 7) % 9;
-            const int nwait = ((t2 == 0 ? C0 : 0) + (t2 < HALO_ROUNDS ? 1 : 0)) + NW +
-                              ((t1 == 0 ? C0 : 0) + (t1 < HALO_ROUNDS ? 1 : 0));
+            static_assert(PF >= 2 && PF <= 3, "the in-place transform of item j runs at tap j+3");
+            int nwait = 0;
+#pragma unroll
+            for (int d = 1; d < PF; ++d) {
+                const int x = (tap + 9 - d) % 9;
+                nwait += (x == 0 ? C0 : 0) + (x < HALO_ROUNDS ? 1 : 0) + NW;
+            }
             // weight tile `tap` has landed; after the barrier it and (at tap 0) the finished halo of this
             // chunk are visible to every wave, and every wave is done with the buffers refilled below
             MAD_STAMP(0)
@@ -285,44 +373,63 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / 2) void conv3x3_halo_kernel
                 case 3: dma_wait_upto<3>(); break;
                 case 4: dma_wait_upto<4>(); break;
                 case 5: dma_wait_upto<5>(); break;
-                default: dma_wait_upto<6>(); break;
+                case 6: dma_wait_upto<6>(); break;
+                case 7: dma_wait_upto<7>(); break;
+                default: dma_wait_upto<8>(); break;
             }
             MAD_STAMP(1)
             __syncthreads();
             MAD_STAMP(2)
-            const unsigned char* wt = wt0 + (tap % NWBUF) * WTILE_BYTES;
-            // The first fragments are requested before the copies are issued (the issue time covers
-            // the LDS latency), and the copies are spread between groups of MFMAs.
-            uint4 af[2][TM], bfr[2][TN];
+            // buffer of K-tile k = 9*cc + tap is k % NWBUF: a compile-time value when NWBUF divides 9
+            auto wbuf = [&](int c_, int t_) { return 9 % NWBUF == 0 ? t_ % NWBUF : (c_ * (9 % NWBUF) + t_) % NWBUF; };
+            const unsigned char* wt = wt0 + wbuf(cc, tap) * WTILE_BYTES;
+            // item tap-3 of the next chunk was issued three taps ago, before weight tile `tap`: it has landed,
+            // and is transformed in place in 16 pieces behind this tap's 16 MFMAs
+            const bool do_x = FUSE && tap >= 3 && tap - 3 < HALO_ROUNDS;
+            static_assert(TM % 2 == 0, "pixel tiles are multiplied in pairs");
+            constexpr int NG = TM;                     // groups of 2*TN MFMAs: (K half, pair of pixel tiles)
+            // bf16: the fragments of a group are requested while the group before it is multiplied (measured
+            // a little faster than requesting all of a tap's fragments at its top); the fp32 parity form has no
+            // registers to spare and requests each group when it needs it
+            constexpr bool AHEAD = sizeof(T) == 2;
+            uint4 afs[2][2], bfs[2][TN];
+            auto read_group = [&](int g) {
+                const int kk = g / (TM / 2), q0 = 2 * (g % (TM / 2));
+                if (q0 == 0) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
-                af[0][i] = *reinterpret_cast<const uint4*>(halo + a_off[kx][0] + (2 * i + ky) * HS * HROW);
+                    for (int q = 0; q < TN; ++q) bfs[kk][q] = *reinterpret_cast<const uint4*>(wt + b_off[q][kk]);
+                }
 #pragma unroll
-            for (int jn = 0; jn < TN; ++jn) bfr[0][jn] = *reinterpret_cast<const uint4*>(wt + b_off[jn][0]);
-            if (tap + 2 < 9) stage_w(cc, tap + 2, (tap + 2) % NWBUF);
-            else stage_w(ccn, tap + 2 - 9, (tap + 2) % NWBUF);
+                for (int q = 0; q < 2; ++q)
+                    afs[g & 1][q] = *reinterpret_cast<const uint4*>(halo + a_off[kx][kk] + (2 * (q0 + q) + ky) * HSX * HROW);
+            };
+            read_group(0);
+            if (do_x) xf_begin(tap - 3, nb);
 #pragma unroll
-            for (int i = 0; i < TM / 2; ++i)
+            for (int g = 0; g < NG; ++g) {
+                const int kk = g / (TM / 2), q0 = 2 * (g % (TM / 2));
+                if (AHEAD ? g + 1 < NG : g > 0) read_group(AHEAD ? g + 1 : g);
 #pragma unroll
-                for (int jn = 0; jn < TN; ++jn) mma_chunk<T>(acc[i][jn], af[0][i], bfr[0][jn]);
-            if (FUSE && tap == 0) dma_coef(ccn, nb);
-            if (tap < HALO_ROUNDS) dma_item(ccn, tap, nb);
+                for (int m = 0; m < 2 * TN; ++m) {
+                    const int sidx = g * 2 * TN + m;
+                    mma_chunk<T>(acc[q0 + m / TN][m % TN], afs[g & 1][m / TN], bfs[kk][m % TN]);
+                    if (sidx == 1) {
+                        if (FUSE && tap == 0) dma_coef(ccn, nb);
+                        if (tap < HALO_ROUNDS) dma_item(ccn, tap, nb);
+                    }
+                    if (sidx == 3 || (2 * TM * TN < 4 && sidx == 2 * TM * TN - 1)) {
+                        if (tap + PF < 9) stage_w(cc, tap + PF, wbuf(cc, tap + PF));
+                        else stage_w(ccn, tap + PF - 9, wbuf(cc + 1, tap + PF - 9));
+                    }
+                    if (do_x) {
+                        constexpr int NS = 2 * TM * TN;           // 16/NS transform pieces per MFMA
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
-                af[1][i] = *reinterpret_cast<const uint4*>(halo + a_off[kx][1] + (2 * i + ky) * HS * HROW);
-#pragma unroll
-            for (int jn = 0; jn < TN; ++jn) bfr[1][jn] = *reinterpret_cast<const uint4*>(wt + b_off[jn][1]);
-#pragma unroll
-            for (int i = TM / 2; i < TM; ++i)
-#pragma unroll
-                for (int jn = 0; jn < TN; ++jn) mma_chunk<T>(acc[i][jn], af[0][i], bfr[0][jn]);
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int jn = 0; jn < TN; ++jn) mma_chunk<T>(acc[i][jn], af[1][i], bfr[1][jn]);
+                        for (int xs = sidx * 16 / NS; xs < (sidx + 1) * 16 / NS; ++xs) xf_slot(xs, tap - 3);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
             MAD_STAMP(3)
-            // item tap-3 of the next chunk was issued three taps ago, before weight tile `tap`: it has landed
-            if (tap >= 3 && tap - 3 < HALO_ROUNDS) xform_item(tap - 3, nb);
             MAD_STAMP(4)
         }
     }
@@ -335,7 +442,7 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / 2) void conv3x3_halo_kernel
     if constexpr (SKIP) {
         const int Cs = a.SC1 + a.SC2;
         const int nskip = Cs / CK;
-        constexpr int SK_ROUNDS = 1024 / NT;
+        constexpr int SK_ROUNDS = TW * 16 * 4 / NT;      // pixels in the order (half, row, column)
         auto dma_skip = [&](int sc, int buf) {
             const int c0 = sc * CK;
             const T* src; int cs, coff;
@@ -346,7 +453,7 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / 2) void conv3x3_halo_kernel
                 const int item = tid + NT * j;
                 const int pp = item >> 2;
                 const int lc = (tid & 3) ^ ((pp >> 2) & 3);
-                const size_t pix = ((size_t)b * a.H + ty0 + (pp >> 4)) * a.W + tx0 + (pp & 15);
+                const size_t pix = ((size_t)b * a.H + ty0 + ((pp >> 4) & 15)) * a.W + tx0 + (pp >> 8) * 16 + (pp & 15);
                 glds16(src + pix * cs + coff + lc * VEC,
                        __builtin_amdgcn_readfirstlane(halo_base + buf * HALO_BUF + (NT * j + 64 * wave) * 16));
             }
@@ -361,7 +468,7 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / 2) void conv3x3_halo_kernel
         };
         int s_off[2];
         {
-            const int r = wm * (256 / WM) + fr;
+            const int r = wm * (TM * 32) + fr;
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) s_off[kk] = r * HROW + (((2 * kk + fh) ^ ((r >> 2) & 3)) << 4);
         }
@@ -389,16 +496,21 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / 2) void conv3x3_halo_kernel
     }
     MAD_STAMP_PHASE(2)
 
-    // ---- epilogue, one half tile (8 tile rows = 128 pixels) at a time
+    // ---- epilogue, 128 pixels (8 rows of one 16-column half) per pass.  Pixels in wave order: L = wm*TM*32 +
+    // tile*32 + row-in-tile = (half, row, column) = (L >> 8, (L >> 4) & 15, L & 15).
     float* ctile = reinterpret_cast<float*>(smem);
-    constexpr int ROWS_PER_WAVE = 256 / WM;                  // pixels owned by one wave row
+    constexpr int WAVE_PIX = TM * 32;                        // pixels owned by one wave
+    constexpr int NPASS = TW * 16 / 128;
+    static_assert(WAVE_PIX <= 128 && 128 % WAVE_PIX == 0, "a wave's pixels lie inside one pass");
+    auto pix_y = [&](int L) { return ty0 + ((L >> 4) & 15); };
+    auto pix_x = [&](int L) { return tx0 + (L >> 8) * 16 + (L & 15); };
     if constexpr (OUT_NCHW) {
         float* yo = (float*)a.y;
 #pragma unroll 1
-        for (int half = 0; half < 2; ++half) {
+        for (int half = 0; half < NPASS; ++half) {
             __syncthreads();
-            if ((wm * ROWS_PER_WAVE) / 128 == half) {
-                const int rbase = wm * ROWS_PER_WAVE - half * 128;
+            if ((wm * WAVE_PIX) / 128 == half) {
+                const int rbase = wm * WAVE_PIX - half * 128;
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -411,7 +523,7 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / 2) void conv3x3_halo_kernel
             __syncthreads();
             if (tid < 128) {
                 const int r = tid;
-                const int oy = ty0 + half * 8 + (r >> 4), ox = tx0 + (r & 15);
+                const int oy = pix_y(half * 128 + r), ox = pix_x(half * 128 + r);
                 for (int n = 0; n < a.Cout; ++n)
                     yo[(((size_t)b * a.Cout + n) * a.H + oy) * a.W + ox] = ctile[r * EPI_LD + n] + a.bias[n];
             }
@@ -426,16 +538,16 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / 2) void conv3x3_halo_kernel
     for (int i = 0; i < VEC; ++i) { bias_v[i] = a.bias ? a.bias[n0 + ec + i] : 0.0f; ssum[i] = 0.0f; ssq[i] = 0.0f; }
     const T* res = (const T*)a.residual;
     T* y = (T*)a.y;
-    constexpr int RPT = 128 / RPP;           // rows per thread per half tile
+    constexpr int RPT = 128 / RPP;           // rows per thread per pass
 #pragma unroll 1
-    for (int half = 0; half < 2; ++half) {
+    for (int half = 0; half < NPASS; ++half) {
         // residual rows of this half are requested first: their latency overlaps the tile hand-over
         uint4 rpre[RPT];
         if (a.res_mode == MAD_RES_SAME || a.res_mode == MAD_RES_UP) {
 #pragma unroll
             for (int k = 0; k < RPT; ++k) {
                 const int r = er + k * RPP;
-                const int oy = ty0 + half * 8 + (r >> 4), ox = tx0 + (r & 15);
+                const int oy = pix_y(half * 128 + r), ox = pix_x(half * 128 + r);
                 const size_t rp = a.res_mode == MAD_RES_SAME
                                       ? ((size_t)b * a.H + oy) * a.W + ox
                                       : ((size_t)b * (a.H >> 1) + (oy >> 1)) * (a.W >> 1) + (ox >> 1);
@@ -444,8 +556,8 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / 2) void conv3x3_halo_kernel
         }
         __syncthreads();
         MAD_STAMP_PHASE(3 + 3 * half)
-        if ((wm * ROWS_PER_WAVE) / 128 == half) {
-            const int rbase = wm * ROWS_PER_WAVE - half * 128;
+        if ((wm * WAVE_PIX) / 128 == half) {
+            const int rbase = wm * WAVE_PIX - half * 128;
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -460,7 +572,7 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / 2) void conv3x3_halo_kernel
 #pragma unroll
         for (int k = 0; k < RPT; ++k) {
             const int r = er + k * RPP;
-            const int oy = ty0 + half * 8 + (r >> 4), ox = tx0 + (r & 15);
+            const int oy = pix_y(half * 128 + r), ox = pix_x(half * 128 + r);
             const size_t m = ((size_t)b * a.H + oy) * a.W + ox;
             float v[VEC];
 #pragma unroll
@@ -519,21 +631,21 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / 2) void conv3x3_halo_kernel
         if (c < a.gC1) { gsrc = (const T*)a.gx1 + c; gcs = a.gC1; }
         else { gsrc = (const T*)a.gx2 + (c - a.gC1); gcs = a.Cout - a.gC1; }
         constexpr int KB = 8;                  // row pairs in flight per batch
-        static_assert((2 * RPT) % KB == 0, "whole batches");
+        static_assert((NPASS * RPT) % KB == 0, "whole batches");
 #pragma unroll 1
-        for (int k0 = 0; k0 < 2 * RPT; k0 += KB) {
+        for (int k0 = 0; k0 < NPASS * RPT; k0 += KB) {
             uint4 xq[KB], gq[KB];
 #pragma unroll
             for (int k = 0; k < KB; ++k) {
                 const int r = er + (k0 + k) * RPP;
-                const size_t m = ((size_t)b * a.H + ty0 + (r >> 4)) * a.W + tx0 + (r & 15);
+                const size_t m = ((size_t)b * a.H + pix_y(r)) * a.W + pix_x(r);
                 xq[k] = *reinterpret_cast<const uint4*>(gsrc + m * gcs);
                 gq[k] = *reinterpret_cast<const uint4*>(y + m * a.Cout + c);
             }
 #pragma unroll
             for (int k = 0; k < KB; ++k) {
                 const int r = er + (k0 + k) * RPP;
-                const size_t m = ((size_t)b * a.H + ty0 + (r >> 4)) * a.W + tx0 + (r & 15);
+                const size_t m = ((size_t)b * a.H + pix_y(r)) * a.W + pix_x(r);
                 float f[VEC], xv[VEC];
                 Vec16<T> gr; gr.raw = gq[k]; gr.unpack(f);
                 Vec16<T> xr; xr.raw = xq[k]; xr.unpack(xv);
@@ -565,7 +677,12 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / 2) void conv3x3_halo_kernel
             const int c = tid >> 1, which = tid & 1;
             float s = 0.0f;
             for (int g = 0; g < RPP; ++g) s += red[(g * BN + c) * 2 + which];
-            a.stats[(((size_t)b * tiles_img + tile) * a.Cout + n0 + c) * 2 + which] = s;
+            // one row of sums per 16x16 tile of the image: a 32-wide workgroup tile writes its sums to the row of
+            // its left half and zeros to the row of its right half (the consumer adds the rows up)
+            const int tile16 = (tile / a.tiles_x) * (a.W / 16) + (tile % a.tiles_x) * (TW / 16);
+            const size_t tiles16_img = (size_t)(a.H / 16) * (a.W / 16);
+            a.stats[((b * tiles16_img + tile16) * a.Cout + n0 + c) * 2 + which] = s;
+            if (TW == 32) a.stats[((b * tiles16_img + tile16 + 1) * a.Cout + n0 + c) * 2 + which] = 0.0f;
         }
     }
     }
@@ -580,15 +697,17 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / 2) void conv3x3_halo_kernel
 #endif
 }
 
-template <typename T, bool FUSE, int WM, int WN, int TN, bool OUT_NCHW, bool SKIP = false, bool GSTAT = false>
-static int launch_halo(const HaloArgs& a, hipStream_t s, const char* what) {
-    constexpr int lds = halo_lds_bytes<WN * TN * 32>();
+template <typename T, bool FUSE, int WM, int WN, int TN, bool OUT_NCHW, bool SKIP = false, bool GSTAT = false, int TW = 16>
+static int launch_halo(const HaloArgs& a0, hipStream_t s, const char* what) {
+    constexpr int lds = halo_lds_bytes<WN * TN * 32, TW>();
     static int lds_dev = -1;
-    MAD_REQUIRE(raise_lds_limit(reinterpret_cast<const void*>(&conv3x3_halo_kernel<T, FUSE, WM, WN, TN, OUT_NCHW, SKIP, GSTAT>),
+    MAD_REQUIRE(raise_lds_limit(reinterpret_cast<const void*>(&conv3x3_halo_kernel<T, FUSE, WM, WN, TN, OUT_NCHW, SKIP, GSTAT, TW>),
                                 lds, &lds_dev),
                 "%s: cannot raise the dynamic LDS limit to %d", what, lds);
+    HaloArgs a = a0;
+    a.tiles_x = a.W / TW;
     const int grid = a.B * a.tiles_x * a.tiles_y * a.ntiles_n;
-    hipLaunchKernelGGL((conv3x3_halo_kernel<T, FUSE, WM, WN, TN, OUT_NCHW, SKIP, GSTAT>), dim3(grid), dim3(64 * WM * WN), lds, s, a);
+    hipLaunchKernelGGL((conv3x3_halo_kernel<T, FUSE, WM, WN, TN, OUT_NCHW, SKIP, GSTAT, TW>), dim3(grid), dim3(64 * WM * WN), lds, s, a);
     return check_launch(what);
 }
 
@@ -618,6 +737,10 @@ static int conv3x3_fused_impl(const void* x1, int C1, const void* x2, int C2, co
     MAD_REQUIRE(B > 0 && H >= 16 && W >= 16 && H % 16 == 0 && W % 16 == 0,
                 "mad_conv3x3_fused: H=%d, W=%d must be multiples of 16", H, W);
     MAD_REQUIRE((size_t)B * H * W < (1u << 31), "mad_conv3x3_fused: tensor too large for 32-bit pixel indices");
+    // the loader-transform form addresses its input with 24-bit pixel indices and 32-bit byte offsets
+    MAD_REQUIRE(!coef || ((size_t)B * H * W < (1u << 24) && (size_t)B * H * W * (C1 > C2 ? C1 : C2) * 4 < ((size_t)1 << 32)),
+                "mad_conv3x3_fused: input of B*H*W = %zu pixels is too large for the fused loader (split the batch)",
+                (size_t)B * H * W);
     MAD_REQUIRE(res_mode >= MAD_RES_NONE && res_mode <= MAD_RES_DOWN && (res_mode == MAD_RES_NONE || residual),
                 "mad_conv3x3_fused: bad residual mode %d", res_mode);
     HaloArgs a;
@@ -650,7 +773,22 @@ static int conv3x3_fused_impl(const void* x1, int C1, const void* x2, int C2, co
         else if (v == 192 && Cout % 128 == 64 && Cout > 64) mode = 192;
         else if (v == 0 && mode == 192) mode = 64;                                 // no split
     }
+    // 16 x 32 pixel tiles on eight waves (one workgroup per CU, half the weight copies per multiply) where the
+    // image is wide enough and such tiles still fill the chip; 16 x 16 tiles on four waves otherwise
+    const bool wide_fits = dtype == MAD_BF16 && !gn && W % 32 == 0;
+    // (measured: a gain of 3-4 % for layers of 256 and more output channels, a loss of 2-3 % at 128, whose
+    // workgroups then have no second workgroup on their CU to overlap their first and last phases with)
+    bool wide_ok = wide_fits && Cout >= 256 && B * (W / 32) * a.tiles_y * (Cout / 128) >= 256;
+    if (const char* f = getenv("MAD_HALO_WIDE"))              // tuning / test aid: 0 = never, 2 = wherever it fits
+        wide_ok = atoi(f) == 2 ? wide_fits : (wide_ok && atoi(f) != 0);
     auto run = [&](bool narrow) -> int {
+        if (wide_ok && !narrow) {
+            if (SC1 > 0)
+                return coef ? launch_halo<bf16_t, true, 4, 2, 2, false, true, false, 32>(a, s, what)
+                            : launch_halo<bf16_t, false, 4, 2, 2, false, true, false, 32>(a, s, what);
+            return coef ? launch_halo<bf16_t, true, 4, 2, 2, false, false, false, 32>(a, s, what)
+                        : launch_halo<bf16_t, false, 4, 2, 2, false, false, false, 32>(a, s, what);
+        }
 #define MAD_HALO_DISPATCH(T_, TN_)                                                                    \
     do {                                                                                              \
         if (gn) return launch_halo<T_, false, 2, 2, TN_, false, false, true>(a, s, what);             \

@@ -50,6 +50,21 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_wave_base)
         : "memory");
 }
 
+// The same copy with a wave-uniform 64-bit base address (held in scalar registers) and a 32-bit byte offset
+// per lane: half the address registers and no 64-bit vector arithmetic per copy.
+__device__ __forceinline__ void glds16s(const void* sbase, unsigned voff, unsigned lds_wave_base) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %3\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %2\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff), "s"(sbase), "s"(lds_wave_base)
+        : "memory");
+}
+
 __device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // Wait until at most N of this wave's vector-memory operations (LDS-DMA included) are outstanding;

@@ -318,15 +318,21 @@ FUSED_CASES = [
 
 @pytest.mark.parametrize("case", FUSED_CASES)
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("bn", ["128", "64", "192"])
+@pytest.mark.parametrize("bn", ["128", "64", "192", "128w", "192w"])
 def test_conv3x3_fused(dev, case, dt, bn, monkeypatch):
-    """Both workgroup widths (128 and 64 output channels) of the halo-tile kernel, and ("192") the split of an
-    odd multiple of 64 channels over a wide and a narrow launch."""
+    """Both workgroup widths (128 and 64 output channels) of the halo-tile kernel, ("192") the split of an
+    odd multiple of 64 channels over a wide and a narrow launch, and ("w") the 16x32-pixel eight-wave tiles
+    forced wherever they fit (bf16, width a multiple of 32, 128-channel workgroups)."""
     from mad_amd import _lib, ops
+    wide = bn.endswith("w")
+    bn = bn.rstrip("w")
     monkeypatch.setenv("MAD_HALO_BN", bn)
+    monkeypatch.setenv("MAD_HALO_WIDE", "2" if wide else "0")
     B, H, C1, C2, Cout, fuse, up, res, want_stats = case
     if bn == "192" and Cout % 128 != 64:
         pytest.skip("the split applies to odd multiples of 64 channels")
+    if wide and (dt != torch.bfloat16 or H % 32):
+        pytest.skip("16x32 tiles: bf16, width a multiple of 32")
     C = C1 + C2
     Hs = H // 2 if up else H
     x1 = _rand((B, C1, Hs, Hs), 1, 1.3) + 0.2
@@ -363,8 +369,12 @@ def test_conv3x3_fused(dev, case, dt, bn, monkeypatch):
     if want_stats:
         yy = _nchw(y).double()                            # statistics are taken over the stored values
         tiles = yy.reshape(B, Cout, H // 16, 16, H // 16, 16).permute(0, 2, 4, 1, 3, 5).reshape(B, -1, Cout, 256)
-        assert rel_err(stats[..., 0].cpu(), tiles.sum(-1)) < 1e-4
-        assert rel_err(stats[..., 1].cpu(), (tiles ** 2).sum(-1)) < 1e-4
+        s0, s1, st = tiles.sum(-1), (tiles ** 2).sum(-1), stats.cpu()
+        if wide:      # a 16x32 tile writes its sums to the row of its left half and zeros to the right half's
+            pair = lambda t: t.reshape(B, H // 16, H // 32, 2, Cout).sum(3)
+            s0, s1, st = pair(s0), pair(s1), st.reshape(B, H // 16, H // 32, 2, Cout, 2).sum(3)
+        assert rel_err(st[..., 0], s0) < 1e-4
+        assert rel_err(st[..., 1], s1) < 1e-4
         # and they feed the finalize kernel exactly like the partial-sum kernel's output does
         gamma, beta = 1 + 0.2 * _rand((Cout,), 8), 0.2 * _rand((Cout,), 9)
         c1 = ops.gn_finalize(stats, H * H, gamma.to(dev), beta.to(dev), 32, 1e-5)
@@ -373,11 +383,13 @@ def test_conv3x3_fused(dev, case, dt, bn, monkeypatch):
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("bn", ["128", "64"])
-@pytest.mark.parametrize("case", [(2, 32, 64, 64, 32, 128), (1, 16, 128, 96, 0, 192)])
+@pytest.mark.parametrize("bn", ["128", "64", "128w"])
+@pytest.mark.parametrize("case", [(2, 32, 64, 64, 32, 128), (1, 16, 128, 96, 0, 192), (1, 64, 64, 32, 64, 256)])
 def test_conv3x3_fused_projection(dev, case, dt, bn, monkeypatch):
     """conv1 + the residual branch's 1x1 projection of the (two-source) block input in one launch."""
     from mad_amd import ops
+    monkeypatch.setenv("MAD_HALO_WIDE", "2" if bn.endswith("w") else "0")
+    bn = bn.rstrip("w")
     monkeypatch.setenv("MAD_HALO_BN", bn)
     B, H, C, S1, S2, Cout = case
     h = _rand((B, C, H, H), 1, 1.2)
