@@ -146,6 +146,17 @@ int mad_conv2d_stats(const void* x1, int C1, const void* x2, int C2, const void*
                      const void* residual, int res_mode, void* y, float* stats, int dtype, int B, int H,
                      int W, int Cout, int ksize, int upsample, void* stream);
 
+/* mad_conv2d / mad_conv2d_stats (stats may be NULL) with a caller-provided device workspace.  Layers with few
+ * output tiles and a long K (the 3x3 layers of the 8x8 stage at small batch) are then cut along K: every share
+ * writes an fp32 partial slab into the workspace and a finishing kernel adds the shares in a fixed order before
+ * bias, residual, rounding and statistics.  mad_conv2d_workspace_bytes returns the size such a layer needs and
+ * 0 for a layer that runs in one pass (then workspace may be NULL).  Same reference lines as mad_conv2d. */
+size_t mad_conv2d_workspace_bytes(int dtype, int B, int H, int W, int Cin, int Cout, int ksize);
+int mad_conv2d_ws(const void* x1, int C1, const void* x2, int C2, const void* w, const float* bias,
+                  const void* residual, int res_mode, void* y, float* stats, int dtype, int B, int H,
+                  int W, int Cout, int ksize, int upsample, void* workspace, size_t workspace_bytes,
+                  void* stream);
+
 /* 3x3 convolution (pad 1, stride 1) for layers with H, W multiples of 16 and Cout a multiple of 64,
  * with the producer's GroupNorm folded into the operand loader and the consumer's GroupNorm
  * statistics produced by the epilogue:

@@ -47,6 +47,9 @@ SIGNATURES = {
                    + [c_int] * 7 + [c_void_p]),
     "mad_conv2d_stats": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
                                  c_void_p] + [c_int] * 7 + [c_void_p]),
+    "mad_conv2d_workspace_bytes": (ctypes.c_size_t, [c_int] * 7),
+    "mad_conv2d_ws": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
+                              c_void_p] + [c_int] * 7 + [c_void_p, ctypes.c_size_t, c_void_p]),
     "mad_conv3x3_fused": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                                   c_int, c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
     "mad_conv3x3_fused_skip": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p,

@@ -25,6 +25,9 @@ struct ConvArgs {
     int Hs, Ws;     // source spatial size (H/2, W/2 when upsample)
     int mtiles, ntiles;
     float* stats;   // optional (M/64, Cout, 2): per-channel sum / sum of squares of each 64-pixel run of the output
+    // split-K form: blockIdx.y takes one of `ksplit` contiguous shares of the K-tiles and writes its fp32 partial
+    // tile to partial[share][M][Cout]; conv_splitk_finish_kernel adds the shares in order and does the epilogue
+    float* partial; int ksplit;
 };
 
 constexpr int ROWB = 128;   // bytes per LDS row = one K-tile of one operand row
@@ -65,7 +68,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
     const int Ctot = a.C1 + a.C2;
     const int cchunks = Ctot / CK;
     const int ntaps = a.ksize * a.ksize;
-    const int nk = ntaps * cchunks;
+    const int nk_all = ntaps * cchunks;
+    const int kt_lo = a.partial ? (int)((long long)nk_all * blockIdx.y / a.ksplit) : 0;
+    const int nk = (a.partial ? (int)((long long)nk_all * (blockIdx.y + 1) / a.ksplit) : nk_all) - kt_lo;
     const int pad = a.ksize >> 1;
     const int HW = a.H * a.W;
 
@@ -125,14 +130,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
     const int frow = lane & 31, fh = lane >> 5;
-    for (int p = 0; p < NST - 1 && p < nk; ++p) stage(p, p);
+    for (int p = 0; p < NST - 1 && p < nk; ++p) stage(kt_lo + p, p);
     int buf = 0, nbuf = NST - 1;                 // buffer of tile kt, buffer tile kt+NST-1 goes to
     for (int kt = 0; kt < nk; ++kt) {
         // tiles kt+1 .. kt+NST-2 may still be in flight; near the end fewer were requested
         if (kt + NST - 2 < nk) dma_wait_upto<(NST - 2) * PPW>();
         else dma_wait_all();
         __syncthreads();
-        if (kt + NST - 1 < nk) stage(kt + NST - 1, nbuf);
+        if (kt + NST - 1 < nk) stage(kt_lo + kt + NST - 1, nbuf);
         const unsigned char* abuf = smem + buf * (A_BYTES + B_BYTES);
         const unsigned char* bbuf = abuf + A_BYTES;
 #pragma unroll
@@ -155,6 +160,23 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
         }
         buf = buf + 1 == NST ? 0 : buf + 1;
         nbuf = nbuf + 1 == NST ? 0 : nbuf + 1;
+    }
+
+    if (a.partial) {
+        // split-K: the raw fp32 accumulators go straight to this share's slab (128 contiguous bytes per row
+        // and half wave); bias, residual, rounding and statistics belong to the finishing kernel
+        float* dst = a.partial + (size_t)blockIdx.y * a.M * a.Cout;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int m = m0 + wm * (BM / 2) + i * 32 + acc_row(e, lane);
+                    const int c = n0 + wn * (BN / 2) + j * 32 + (lane & 31);
+                    if (m < a.M) dst[(size_t)m * a.Cout + c] = acc[i][j][e];
+                }
+        return;
     }
 
     // ---- epilogue: fp32 tile -> LDS -> coalesced 16-byte stores with bias / residual
@@ -270,6 +292,96 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
                 for (int g = 0; g < RPP; ++g) t += red[(g * BN + c) * 2 + which];
                 a.stats[((size_t)(m0 / 64 + h) * a.Cout + n0 + c) * 2 + which] = t;
             }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------- split-K finish
+// grid (M/64 rounded up, Cout/64), 256 threads: one 64-pixel run x 64 output channels.  Adds the ksplit fp32
+// partial slabs in share order (fixed: the result does not depend on which workgroup finished first), then bias,
+// residual, rounding to T, the store, and the run's per-channel sum / sum of squares, as the one-pass epilogue.
+template <typename T>
+__global__ __launch_bounds__(256) void conv_splitk_finish_kernel(ConvArgs a) {
+    constexpr int VEC = Elem<T>::VEC;
+    constexpr int CPR = 64 / VEC, RPP = 256 / CPR, NPASS = 64 / RPP;
+    __shared__ float red[RPP * 64 * 2];
+    const int tid = threadIdx.x;
+    const int er = tid / CPR, ec = (tid % CPR) * VEC;
+    const int m0 = blockIdx.x * 64, n0 = blockIdx.y * 64;
+    const int HW = a.H * a.W;
+    const T* res = (const T*)a.residual;
+    T* y = (T*)a.y;
+    const size_t slab = (size_t)a.M * a.Cout;
+    float bias_v[VEC], ssum[VEC], ssq[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) { bias_v[i] = a.bias ? a.bias[n0 + ec + i] : 0.0f; ssum[i] = 0.0f; ssq[i] = 0.0f; }
+#pragma unroll
+    for (int k = 0; k < NPASS; ++k) {
+        const int m = m0 + er + k * RPP;
+        if (m >= a.M) break;
+        float v[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) v[i] = 0.0f;
+        const float* p = a.partial + (size_t)m * a.Cout + n0 + ec;
+        for (int sidx = 0; sidx < a.ksplit; ++sidx) {
+#pragma unroll
+            for (int i = 0; i < VEC; i += 4) {
+                const float4 t = *reinterpret_cast<const float4*>(p + sidx * slab + i);
+                v[i] += t.x; v[i + 1] += t.y; v[i + 2] += t.z; v[i + 3] += t.w;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) v[i] += bias_v[i];
+        if (a.res_mode == MAD_RES_SAME) {
+            Vec16<T> rv; rv.load(res + (size_t)m * a.Cout + n0 + ec);
+            float f[VEC]; rv.unpack(f);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) v[i] += f[i];
+        } else if (a.res_mode == MAD_RES_UP) {
+            const int b = m / HW, rem = m - b * HW, oy = rem / a.W, ox = rem - oy * a.W;
+            const size_t rp = ((size_t)b * (a.H >> 1) + (oy >> 1)) * (a.W >> 1) + (ox >> 1);
+            Vec16<T> rv; rv.load(res + rp * a.Cout + n0 + ec);
+            float f[VEC]; rv.unpack(f);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) v[i] += f[i];
+        } else if (a.res_mode == MAD_RES_DOWN) {
+            const int b = m / HW, rem = m - b * HW, oy = rem / a.W, ox = rem - oy * a.W;
+            float s[VEC];
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) s[i] = 0.0f;
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 2; ++dx) {
+                    const size_t rp = ((size_t)b * (2 * a.H) + (2 * oy + dy)) * (2 * a.W) + (2 * ox + dx);
+                    Vec16<T> rv; rv.load(res + rp * a.Cout + n0 + ec);
+                    float f[VEC]; rv.unpack(f);
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) s[i] += f[i];
+                }
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) v[i] = fmaf(s[i], 0.25f, v[i]);
+        }
+        Vec16<T> o; o.pack(v);
+        o.store(y + (size_t)m * a.Cout + n0 + ec);
+        if (a.stats) {
+            float f[VEC]; o.unpack(f);              // statistics of the values as stored
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) { ssum[i] += f[i]; ssq[i] = fmaf(f[i], f[i], ssq[i]); }
+        }
+    }
+    if (a.stats) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            red[(er * 64 + ec + i) * 2] = ssum[i];
+            red[(er * 64 + ec + i) * 2 + 1] = ssq[i];
+        }
+        __syncthreads();
+        if (tid < 128) {
+            const int c = tid >> 1, which = tid & 1;
+            float t = 0.0f;
+            for (int g = 0; g < RPP; ++g) t += red[(g * 64 + c) * 2 + which];
+            a.stats[((size_t)blockIdx.x * a.Cout + n0 + c) * 2 + which] = t;
         }
     }
 }
@@ -468,8 +580,30 @@ template <typename T, int BM, int BN, int NST> static int launch_igemm(ConvArgs 
                 "mad_conv2d: cannot raise the dynamic LDS limit to %d", lds);
     a.mtiles = (a.M + BM - 1) / BM;
     a.ntiles = a.Cout / BN;
-    hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, NST>), dim3(a.mtiles * a.ntiles), dim3(256), lds, s, a);
+    const int shares = a.partial ? a.ksplit : 1;
+    hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, NST>), dim3(a.mtiles * a.ntiles, shares), dim3(256), lds, s, a);
+    if (a.partial) {
+        hipLaunchKernelGGL((conv_splitk_finish_kernel<T>), dim3((a.M + 63) / 64, a.Cout / 64), dim3(256), 0, s, a);
+    }
     return check_launch("mad_conv2d");
+}
+
+// Split-K plan.  A layer whose 128-row tiles do not put two workgroups on every CU, but whose K is long (the 3x3
+// layers of the 8x8 stage: 4096 pixels x 768 channels with K = 6912 ...), is cut along K into 2, 4 or 8 shares:
+// the smallest count that puts two workgroups on every CU, every share keeping at least 8 K-tiles.  (Measured
+// on the 4096 x 768 x 6912 layer: 122 us in one pass, 94 / 85 / 91 us with 2 / 4 / 8 shares; odd counts leave a
+// partial last round of workgroups and are slower than either neighbour.)  Returns 1 when the one-pass kernel
+// is the better choice: short K (1x1 layers), or enough tiles.
+static int plan_ksplit(int M, int Cout, int Cin, int ksize, int dtype) {
+    if (const char* e = getenv("MAD_IGEMM_KSPLIT")) return std::max(1, atoi(e));     // tuning aid
+    const int ck = dtype == MAD_BF16 ? 64 : 32;
+    const int nk = ksize * ksize * (Cin / ck);
+    const int tiles = ((M + 127) / 128) * (Cout % 128 == 0 ? Cout / 128 : Cout / 64);
+    if (tiles >= 512 || nk < 32) return 1;
+    int s = 2;
+    while (tiles * s < 512 && s < 8) s *= 2;
+    while (s > 1 && nk / s < 8) s /= 2;
+    return s;
 }
 
 // Tile choice: 128x128 tiles when they fill the chip at least once; else 64x128 if those do; otherwise
@@ -477,6 +611,8 @@ template <typename T, int BM, int BN, int NST> static int launch_igemm(ConvArgs 
 template <typename T> static int dispatch_igemm(const ConvArgs& a, hipStream_t s) {
     const char* force = getenv("MAD_IGEMM_TILE");      // tuning aid: "128x128x2", "64x64x4", ...
     const std::string f = force ? force : "";
+    if (a.partial && f.empty())
+        return a.Cout % 128 == 0 ? launch_igemm<T, 128, 128, 2>(a, s) : launch_igemm<T, 128, 64, 2>(a, s);
     const int big_blocks = ((a.M + 127) / 128) * (a.Cout / 128);
     const bool wide = a.Cout % 128 == 0;
     if (f == "128x128x2" && wide) return launch_igemm<T, 128, 128, 2>(a, s);
@@ -497,7 +633,8 @@ using namespace mad;
 
 static int conv2d_impl(const void* x1, int C1, const void* x2, int C2, const void* w, const float* bias,
                        const void* residual, int res_mode, void* y, float* stats, int dtype, int B, int H, int W,
-                       int Cout, int ksize, int upsample, void* stream) {
+                       int Cout, int ksize, int upsample, void* stream, void* workspace = nullptr,
+                       size_t workspace_bytes = 0) {
     MAD_REQUIRE(x1 && w && y, "mad_conv2d: null pointer");
     MAD_REQUIRE(dtype == MAD_BF16 || dtype == MAD_F32, "mad_conv2d: bad dtype %d", dtype);
     MAD_REQUIRE(ksize == 1 || ksize == 3, "mad_conv2d: ksize must be 1 or 3, got %d", ksize);
@@ -513,6 +650,16 @@ static int conv2d_impl(const void* x1, int C1, const void* x2, int C2, const voi
     a.x1 = x1; a.x2 = C2 ? x2 : x1; a.w = w; a.bias = bias; a.residual = residual; a.y = y;
     a.C1 = C1; a.C2 = C2; a.B = B; a.H = H; a.W = W; a.Cout = Cout; a.ksize = ksize; a.upsample = upsample;
     a.res_mode = res_mode; a.M = B * H * W; a.stats = stats;
+    a.partial = nullptr; a.ksplit = 1;
+    if (workspace) {
+        const int ks = plan_ksplit(a.M, Cout, C1 + C2, ksize, dtype);
+        if (ks > 1) {
+            MAD_REQUIRE((size_t)ks * a.M * Cout * sizeof(float) <= workspace_bytes,
+                        "mad_conv2d_ws: workspace of %zu bytes is below mad_conv2d_workspace_bytes (%zu)",
+                        workspace_bytes, (size_t)ks * a.M * Cout * sizeof(float));
+            a.partial = (float*)workspace; a.ksplit = ks;
+        }
+    }
     MAD_REQUIRE(!stats || (H * W) % 64 == 0, "mad_conv2d_stats: H*W=%d must be a multiple of 64", H * W);
     a.Hs = upsample ? H / 2 : H; a.Ws = upsample ? W / 2 : W;
     hipStream_t s = (hipStream_t)stream;
@@ -532,6 +679,20 @@ extern "C" int mad_conv2d_stats(const void* x1, int C1, const void* x2, int C2, 
     MAD_REQUIRE(stats, "mad_conv2d_stats: null statistics pointer");
     return conv2d_impl(x1, C1, x2, C2, w, bias, residual, res_mode, y, stats, dtype, B, H, W, Cout, ksize, upsample,
                        stream);
+}
+
+extern "C" size_t mad_conv2d_workspace_bytes(int dtype, int B, int H, int W, int Cin, int Cout, int ksize) {
+    if ((dtype != MAD_BF16 && dtype != MAD_F32) || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return 0;
+    const int ks = plan_ksplit(B * H * W, Cout, Cin, ksize, dtype);
+    return ks > 1 ? (size_t)ks * B * H * W * Cout * sizeof(float) : 0;
+}
+
+extern "C" int mad_conv2d_ws(const void* x1, int C1, const void* x2, int C2, const void* w, const float* bias,
+                             const void* residual, int res_mode, void* y, float* stats, int dtype, int B, int H,
+                             int W, int Cout, int ksize, int upsample, void* workspace, size_t workspace_bytes,
+                             void* stream) {
+    return conv2d_impl(x1, C1, x2, C2, w, bias, residual, res_mode, y, stats, dtype, B, H, W, Cout, ksize, upsample,
+                       stream, workspace, workspace_bytes);
 }
 
 extern "C" int mad_conv_in(const float* x, const float* w, const float* bias, void* y, int dtype, int B, int Cin,

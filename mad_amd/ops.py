@@ -260,17 +260,16 @@ def conv2d(x1: Tensor, w: Tensor, bias: Optional[Tensor], x2: Optional[Tensor] =
         raise ValueError("res_mode set without a residual tensor")
     y = torch.empty((B, H, W_, Cout), dtype=x1.dtype, device=x1.device)
     end = TIMER.bracket("conv_igemm", 2.0 * B * H * W_ * Cout * (C1 + C2) * k * k)
+    stats = None
     if want_stats:
         if (H * W_) % 64:
             raise ValueError(f"conv2d statistics need H*W ({H * W_}) to be a multiple of 64")
         stats = torch.empty((B, H * W_ // 64, Cout, 2), dtype=torch.float32, device=x1.device)
-        check(lib.mad_conv2d_stats(_ptr(x1), C1, _ptr(x2), C2, _ptr(w), _ptr(bias), _ptr(residual), res_mode, _ptr(y),
-                                   _ptr(stats), _dtype_code(x1), B, H, W_, Cout, k, int(upsample), _stream()),
-              "mad_conv2d_stats")
-    else:
-        stats = None
-        check(lib.mad_conv2d(_ptr(x1), C1, _ptr(x2), C2, _ptr(w), _ptr(bias), _ptr(residual), res_mode, _ptr(y),
-                             _dtype_code(x1), B, H, W_, Cout, k, int(upsample), _stream()), "mad_conv2d")
+    ws_bytes = lib.mad_conv2d_workspace_bytes(_dtype_code(x1), B, H, W_, C1 + C2, Cout, k)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x1.device) if ws_bytes else None
+    check(lib.mad_conv2d_ws(_ptr(x1), C1, _ptr(x2), C2, _ptr(w), _ptr(bias), _ptr(residual), res_mode, _ptr(y),
+                            _ptr(stats), _dtype_code(x1), B, H, W_, Cout, k, int(upsample), _ptr(ws), ws_bytes,
+                            _stream()), "mad_conv2d_ws")
     if end is not None:
         end.record()
     return (y, stats) if want_stats else y

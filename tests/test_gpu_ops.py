@@ -169,16 +169,20 @@ CONV_CASES = [
     (2, 8, 128, 64, 256, 1, False, "none"),     # 1x1 over a concat
     (1, 32, 192, 0, 576, 1, False, "same"),
     (2, 64, 128, 0, 128, 3, False, "same"),     # several tiles, several rows per tile
+    (16, 8, 256, 0, 256, 3, False, "same"),     # few tiles, long K: the dispatcher cuts K into shares by itself
 ]
 
 
 @pytest.mark.parametrize("case", CONV_CASES)
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("tile", ["auto", "128x128x2", "128x64x2", "64x128x3"])
+@pytest.mark.parametrize("tile", ["auto", "128x128x2", "128x64x2", "64x128x3", "split3"])
 def test_conv2d(dev, case, dt, tile, monkeypatch):
-    """Every block-tile variant the dispatcher can pick (small inputs alone would only reach 64x64)."""
+    """Every block-tile variant the dispatcher can pick (small inputs alone would only reach 64x64), and the
+    split-K form (three shares of the K-tiles, some of them empty for the short layers)."""
     from mad_amd import _lib, ops
-    if tile != "auto":
+    if tile == "split3":
+        monkeypatch.setenv("MAD_IGEMM_KSPLIT", "3")
+    elif tile != "auto":
         monkeypatch.setenv("MAD_IGEMM_TILE", tile)
     B, H, C1, C2, Cout, k, up, res = case
     Hs = H // 2 if up else H
