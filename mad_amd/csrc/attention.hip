@@ -6,6 +6,7 @@
 // exchange) and the probability tile is already laid out as the B operand of the second product
 // O^T = V^T . P^T -- no shuffle or LDS round trip for P.  fp32 softmax, fp32 accumulation.
 #include "mma.h"
+#include <cstdlib>
 
 namespace mad {
 
@@ -186,6 +187,197 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(const T* __restrict_
         }
 }
 
+// ------------------------------------------------------------------------------- bf16 form
+// The same algorithm arranged for the vector-issue budget of the bf16 case, where the softmax (not the
+// matrix pipe) sets the pace at head_dim 64: per score element one multiply-add, one exp2, one add and
+// half a conversion are all that is left in the tile loop.
+//   * 64-key tiles, two K/V buffers in LDS, ONE barrier per tile: tile t+1 is fetched into registers
+//     before the products of tile t and written to the other buffer after them.
+//   * exp2 domain: p = exp2(s*log2(e) - m2), the scale and the running maximum folded into one fma.
+//   * The running maximum moves only when a tile's maximum exceeds it by more than RESCALE_THR (a
+//     wave-uniform decision): p is then bounded by 2^RESCALE_THR instead of 1, which fp32 sums and the
+//     bf16 probabilities (same relative precision at any scale) absorb, and the O-wide rescale runs on a
+//     few tiles per query block instead of on all of them.
+//   * The tile maximum is a chain of three-input maxima; the halves of a query's keys meet through one
+//     lane swap.
+constexpr int KT2 = 64;
+#ifndef MAD_ATTN_THR
+#define MAD_ATTN_THR 0.0f
+#endif
+constexpr float RESCALE_THR = MAD_ATTN_THR;
+
+__device__ __forceinline__ float max3f(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void attention_bf16_kernel(const bf16_t* __restrict__ qkv,
+                                                                  bf16_t* __restrict__ out,
+                                                                  float* __restrict__ lse, int L, int heads) {
+    constexpr int ROW = 128, VROW = 192, CHUNKS = 8, VEC = 8;
+    constexpr int NT = NW * 64;
+    constexpr int K_BYTES = KT2 * ROW, V_BYTES = KT2 * VROW;
+    __shared__ __attribute__((aligned(16))) unsigned char k_lds[2 * K_BYTES];
+    __shared__ __attribute__((aligned(16))) unsigned char v_lds[2 * V_BYTES];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.z, head = blockIdx.y;
+    const int C3 = heads * 3 * HD;
+    const int q0 = (blockIdx.x * NW + wave) * 32;
+    const int qi = lane & 31, fh = lane >> 5;
+    const bf16_t* base = qkv + (size_t)b * L * C3 + head * 3 * HD;
+
+    // Q fragments (B operand), scaled by 1/sqrt(64): exact in bf16
+    uint4 qf[4];
+    {
+        const bf16_t* qrow = base + (size_t)(q0 + qi) * C3;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            Vec16<bf16_t> v;
+            v.load(qrow + (2 * kk + fh) * VEC);
+            float f[VEC];
+            v.unpack(f);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) f[i] *= 0.125f;
+            v.pack(f);
+            qf[kk] = v.raw;
+        }
+    }
+
+    f32x16 o[2];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { o[0][e] = 0.0f; o[1][e] = 0.0f; }
+    float m2 = -1.0e30f, l_run = 0.0f;          // running maximum in exp2 units, running sum
+    constexpr float LOG2E = 1.44269504088896340736f;
+
+    // a tile is 64 keys x (8 K chunks + 8 V chunks) of 16 bytes
+    constexpr int PER_THREAD = KT2 * CHUNKS / NT;
+    static_assert(KT2 * CHUNKS % NT == 0, "whole chunks per thread");
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 kreg[PER_THREAD], vreg[PER_THREAD];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < PER_THREAD; ++i) {
+            const int c = tid + i * NT;
+            const int r = c / CHUNKS, ch = c % CHUNKS;
+            const bf16_t* krow = base + (size_t)(k0 + r) * C3 + HD;
+            kreg[i] = *reinterpret_cast<const u32x4*>(krow + ch * VEC);
+            vreg[i] = *reinterpret_cast<const u32x4*>(krow + HD + ch * VEC);
+        }
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < PER_THREAD; ++i) {
+            const int c = tid + i * NT;
+            const int r = c / CHUNKS, ch = c % CHUNKS;
+            *reinterpret_cast<u32x4*>(k_lds + buf * K_BYTES + r * ROW + ((ch ^ ((r >> 1) & 7)) << 4)) = kreg[i];
+            *reinterpret_cast<u32x4*>(v_lds + buf * V_BYTES + r * VROW + ch * 16) = vreg[i];
+        }
+    };
+    fetch(0);
+    stash(0);
+    __syncthreads();
+
+    const int ntiles = L / KT2;
+    for (int t = 0; t < ntiles; ++t) {
+        const unsigned char* kb = k_lds + (t & 1) * K_BYTES;
+        const unsigned char* vb = v_lds + (t & 1) * V_BYTES;
+        // (the last tile fetches itself again and parks it in the idle buffer: no branch around the copies)
+        fetch((t + 1 < ntiles ? t + 1 : t) * KT2);
+
+        // S^T[key][query] for the two 32-key blocks of the tile
+        f32x16 s[2];
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) s[blk][e] = 0.0f;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const int ch = 2 * kk + fh;
+                const int r = blk * 32 + qi;
+                const uint4 kf = *reinterpret_cast<const uint4*>(kb + r * ROW + ((ch ^ ((r >> 1) & 7)) << 4));
+                mma_chunk<bf16_t>(s[blk], kf, qf[kk]);
+            }
+        }
+
+        // this lane's query: 32 of the tile's keys here, the other 32 in lane^32
+        float tmax = max3f(s[0][0], s[0][1], s[0][2]);
+#pragma unroll
+        for (int e = 3; e < 15; e += 2) tmax = max3f(tmax, s[0][e], s[0][e + 1]);
+        tmax = max3f(tmax, s[0][15], s[1][0]);
+#pragma unroll
+        for (int e = 1; e < 15; e += 2) tmax = max3f(tmax, s[1][e], s[1][e + 1]);
+        tmax = fmaxf(tmax, s[1][15]);
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+        const float t2 = tmax * LOG2E;
+        if (__builtin_amdgcn_ballot_w64(t2 > m2 + RESCALE_THR) != 0) {      // wave-uniform
+            const float m_new = fmaxf(m2, t2);
+            const float alpha = __builtin_amdgcn_exp2f(m2 - m_new);
+            l_run *= alpha;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { o[0][e] *= alpha; o[1][e] *= alpha; }
+            m2 = m_new;
+        }
+        float psum0 = 0.0f, psum1 = 0.0f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            s[0][e] = __builtin_amdgcn_exp2f(fmaf(s[0][e], LOG2E, -m2));
+            s[1][e] = __builtin_amdgcn_exp2f(fmaf(s[1][e], LOG2E, -m2));
+            psum0 += s[0][e];
+            psum1 += s[1][e];
+        }
+        l_run += psum0 + psum1;
+
+        // O^T[d][query] += sum_key V[key][d] * P^T[key][query]; k-step st of block blk uses accumulator
+        // registers 8st..8st+7 as the B fragment: element j of lane half h is key 32blk + 16st + 8(j>>2) + 4h
+        // + (j&3), and the A fragment gathers V^T at those keys with two transposed 4-key x 16-d reads
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                bf16x8 pf;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pf[j] = (__bf16)s[blk][8 * st + j];
+#pragma unroll
+                for (int dh = 0; dh < 2; ++dh) {
+                    const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+                    const int dcol = dh * 32 + (g & 1) * 16 + 4 * pp;
+                    const int krow0 = 32 * blk + 16 * st + 4 * (g >> 1) + q;
+                    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+                    typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+                    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(vb + krow0 * VROW + dcol * 2));
+                    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(vb + (krow0 + 8) * VROW + dcol * 2));
+                    const bf16x8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    o[dh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[dh], 0, 0, 0);
+                }
+            }
+
+        stash((t + 1) & 1);
+        __syncthreads();     // tile t+1 is visible, and nobody still reads the buffer tile t+2 will overwrite
+    }
+
+    const float l = l_run + __shfl_xor(l_run, 32);
+    const float inv = 1.0f / l;
+    const int C = heads * HD;
+    // natural-log sum-exp of the query's scaled scores (what the backward rebuilds the probabilities from)
+    if (lse && fh == 0) lse[((size_t)b * heads + head) * L + q0 + qi] = m2 * 0.69314718055994530942f + __logf(l);
+    bf16_t* orow = out + ((size_t)b * L + q0 + qi) * C + head * HD;
+#pragma unroll
+    for (int dh = 0; dh < 2; ++dh)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int d = dh * 32 + 8 * g + 4 * fh;
+            ushort4 pk;
+            pk.x = f32_to_bf16(o[dh][4 * g + 0] * inv);
+            pk.y = f32_to_bf16(o[dh][4 * g + 1] * inv);
+            pk.z = f32_to_bf16(o[dh][4 * g + 2] * inv);
+            pk.w = f32_to_bf16(o[dh][4 * g + 3] * inv);
+            *reinterpret_cast<ushort4*>(orow + d) = pk;
+        }
+}
+
 }  // namespace mad
 
 using namespace mad;
@@ -196,6 +388,16 @@ static int attention_impl(const void* qkv, void* out, float* lse, int dtype, int
     MAD_REQUIRE(dtype == MAD_BF16 || dtype == MAD_F32, "%s: bad dtype %d", who, dtype);
     MAD_REQUIRE(B > 0 && heads > 0 && L >= 64 && L % 64 == 0, "%s: L=%d must be a multiple of 64", who, L);
     hipStream_t s = (hipStream_t)stream;
+    static const bool old_form = getenv("MAD_ATTN_OLD") != nullptr;      // tuning aid: the generic kernel for bf16 too
+    if (dtype == MAD_BF16 && !old_form) {
+        if (L % 128 == 0)
+            hipLaunchKernelGGL((attention_bf16_kernel<4>), dim3(L / 128, heads, B), dim3(256), 0, s, (const bf16_t*)qkv,
+                               (bf16_t*)out, lse, L, heads);
+        else
+            hipLaunchKernelGGL((attention_bf16_kernel<2>), dim3(L / 64, heads, B), dim3(128), 0, s, (const bf16_t*)qkv,
+                               (bf16_t*)out, lse, L, heads);
+        return check_launch(who);
+    }
     if (L % 128 == 0) {
         dim3 grid(L / 128, heads, B);
         if (dtype == MAD_BF16)

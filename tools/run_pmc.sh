@@ -4,7 +4,7 @@ set -u
 OUT=$1; shift
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-P="python3 $GRAFT_REPO_ROOT/tools/pmc_conv.py $*"
+P="python3 $GRAFT_REPO_ROOT/tools/${PMC_SCRIPT:-pmc_conv.py} $*"
 run() { name=$1; shift; timeout -s KILL 120 rocprofv3 --pmc "$@" --output-format csv -d "$OUT/$name" -- $P > "$OUT/$name.log" 2>&1 || { echo "pass $name failed"; tail -3 "$OUT/$name.log"; exit 1; }; }
 run p1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE
 run p2 SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_INSTS_VALU_TRANS_F32
