@@ -108,6 +108,15 @@ int mad_pos_embedding(const float* t, int t_count, const float* freqs, float* em
 int mad_conv_in(const float* x, const float* w, const float* bias, void* y, int dtype, int B,
                 int Cin, int H, int W, int Cout, void* stream);
 
+/* mad_conv_in that also writes the GroupNorm partial sums of its output: stats fp32 (B, (H/8)*(W/16), Cout, 2),
+ * per-channel sum / sum of squares of every 8x16-pixel tile (tile = ty*(W/16)+tx), as mad_gn_finalize consumes
+ * them with nsplit = (H/8)*(W/16).  Only for shapes mad_conv_in_stats_ok accepts (H % 8 == 0, W % 16 == 0,
+ * Cout in {32, 64, 96, 128, 192, 256}).  Replaces the statistics pass of the first block's GroupNorm
+ * (model.py:182-190). */
+int mad_conv_in_stats_ok(int dtype, int H, int W, int Cout);
+int mad_conv_in_stats(const float* x, const float* w, const float* bias, void* y, float* stats, int dtype,
+                      int B, int Cin, int H, int W, int Cout, void* stream);
+
 /* Last convolution: x NHWC (B,H,W,Cin) -> y NCHW fp32 (B,Cout<=4,H,W), 3x3 pad 1, fp32 weights
  * laid out (Cout,3,3,Cin) and bias.  Replaces out_conv (model.py:549-551, 589). */
 int mad_conv_out(const void* x, int dtype, const float* w, const float* bias, float* y, int B,

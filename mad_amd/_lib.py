@@ -40,6 +40,8 @@ SIGNATURES = {
     "mad_linear_f32": (c_int, [c_void_p] * 4 + [c_int] * 6 + [c_void_p]),
     "mad_pos_embedding": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "mad_conv_in": (c_int, [c_void_p] * 4 + [c_int] * 6 + [c_void_p]),
+    "mad_conv_in_stats_ok": (c_int, [c_int] * 4),
+    "mad_conv_in_stats": (c_int, [c_void_p] * 5 + [c_int] * 6 + [c_void_p]),
     "mad_conv_out": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p] + [c_int] * 5 + [c_void_p]),
     "mad_conv_out_fused": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p] + [c_int] * 5
                            + [c_void_p]),

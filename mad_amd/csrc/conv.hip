@@ -461,17 +461,21 @@ __global__ __launch_bounds__(256) void conv_in_kernel(const float* __restrict__ 
 // workgroup.  Per tile: the 3 x 10 x 18 input halo goes to LDS; each wave owns two tile rows (32
 // pixels) x all Cout channels, reads its A operand straight from the halo at the tap's offset, and
 // writes its 32 x Cout result through a wave-private LDS slab as whole 16-byte chunks (NHWC rows of
-// one tile row are contiguous in memory).
+// one tile row are contiguous in memory).  With `stats` the per-channel sum / sum of squares of the stored
+// values of every tile go to stats[b][tile][Cout][2] (the next GroupNorm's partial sums): lane-local over a
+// wave's 32 pixels, then the four waves are added in order one tile later, behind the barrier the next tile's
+// halo needs anyway.
 template <typename T, int TN>
 __global__ __launch_bounds__(256) void conv_in_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                            const float* __restrict__ bias, T* __restrict__ y, int B,
-                                                            int H, int W) {
+                                                            const float* __restrict__ bias, T* __restrict__ y,
+                                                            float* __restrict__ stats, int B, int H, int W) {
     constexpr int Cout = TN * 32, WP = 29, VEC = Elem<T>::VEC;
     constexpr int HALO_N = 3 * 10 * 18;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_m[];
     float* wl = reinterpret_cast<float*>(smem_m);                  // [Cout][WP]
     float* halo = wl + Cout * WP;                                  // [3][10][18]
     T* oslab = reinterpret_cast<T*>(halo + ((HALO_N + 3) & ~3));   // [4 waves][32][Cout]
+    float* red = reinterpret_cast<float*>(oslab + 4 * 32 * Cout);  // [4 waves][Cout][2]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int i = tid; i < Cout * WP; i += 256) {
         const int n = i / WP, k = i - n * WP;
@@ -492,10 +496,17 @@ __global__ __launch_bounds__(256) void conv_in_mfma_kernel(const float* __restri
     const int tiles_x = W / 16, tiles_y = H / 8;
     const int ntiles = B * tiles_x * tiles_y;
     T* const my_slab = oslab + wave * 32 * Cout;
+    auto flush_stats = [&](int tile) {       // the four waves' sums of `tile`, added in wave order
+        for (int i = tid; i < 2 * Cout; i += 256)
+            stats[(size_t)tile * 2 * Cout + i] = ((red[i] + red[2 * Cout + i]) + red[4 * Cout + i]) + red[6 * Cout + i];
+    };
+    int prev = -1;
     for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
         const int b = t / (tiles_x * tiles_y), tt = t - b * tiles_x * tiles_y;
         const int ty0 = (tt / tiles_x) * 8, tx0 = (tt % tiles_x) * 16;
         __syncthreads();                     // previous tile's halo reads are done (and the weights are in)
+        if (stats && prev >= 0) flush_stats(prev);
+        prev = t;
         for (int i = tid; i < HALO_N; i += 256) {
             const int c = i / 180, r = i - c * 180, hy = r / 18, hx = r - hy * 18;
             const int iy = ty0 - 1 + hy, ix = tx0 - 1 + hx;
@@ -522,6 +533,23 @@ __global__ __launch_bounds__(256) void conv_in_mfma_kernel(const float* __restri
 #pragma unroll
             for (int e = 0; e < 16; ++e)
                 my_slab[acc_row(e, lane) * Cout + jn * 32 + row] = Elem<T>::store(acc[jn][e]);
+        if (stats) {
+            // this lane's channel jn*32+row over the 16 pixels of its half, of the values as stored
+#pragma unroll
+            for (int jn = 0; jn < TN; ++jn) {
+                float sm = 0.0f, sq = 0.0f;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const float f = Elem<T>::load(Elem<T>::store(acc[jn][e]));
+                    sm += f; sq = fmaf(f, f, sq);
+                }
+                sm += __shfl_xor(sm, 32); sq += __shfl_xor(sq, 32);
+                if (kh == 0) {
+                    red[(wave * Cout + jn * 32 + row) * 2] = sm;
+                    red[(wave * Cout + jn * 32 + row) * 2 + 1] = sq;
+                }
+            }
+        }
         __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the slab is private to this wave
         __builtin_amdgcn_wave_barrier();
         constexpr int CHUNKS = 32 * Cout / VEC;           // 16-byte chunks of the slab
@@ -534,6 +562,10 @@ __global__ __launch_bounds__(256) void conv_in_mfma_kernel(const float* __restri
             *reinterpret_cast<uint4*>(y + (((size_t)b * H + oy) * W + ox) * Cout + cv * VEC) = v;
         }
         __builtin_amdgcn_wave_barrier();
+    }
+    if (stats && prev >= 0) {
+        __syncthreads();
+        flush_stats(prev);
     }
 }
 
@@ -695,8 +727,17 @@ extern "C" int mad_conv2d_ws(const void* x1, int C1, const void* x2, int C2, con
                        stream, workspace, workspace_bytes);
 }
 
-extern "C" int mad_conv_in(const float* x, const float* w, const float* bias, void* y, int dtype, int B, int Cin,
-                           int H, int W, int Cout, void* stream) {
+// Shapes the matrix-pipe form of the first layer covers (the only form that can take statistics).
+static bool conv_in_mfma_ok(int dtype, int H, int W, int Cout) {
+    const size_t esz = dtype == MAD_BF16 ? 2 : 4;
+    const size_t lds_m = ((size_t)Cout * 29 + 544) * sizeof(float) + (size_t)4 * 32 * Cout * esz + (size_t)8 * Cout * 4;
+    const int tn = Cout / 32;
+    return H % 8 == 0 && W % 16 == 0 && Cout % 32 == 0 && lds_m <= 160 * 1024 &&
+           (tn == 1 || tn == 2 || tn == 3 || tn == 4 || tn == 6 || tn == 8);
+}
+
+static int conv_in_impl(const float* x, const float* w, const float* bias, void* y, float* stats, int dtype, int B,
+                        int Cin, int H, int W, int Cout, void* stream) {
     MAD_REQUIRE(x && w && bias && y, "mad_conv_in: null pointer");
     MAD_REQUIRE(dtype == MAD_BF16 || dtype == MAD_F32, "mad_conv_in: bad dtype %d", dtype);
     MAD_REQUIRE(Cin == 3, "mad_conv_in: Cin=%d, only 3 input channels are built", Cin);
@@ -704,12 +745,15 @@ extern "C" int mad_conv_in(const float* x, const float* w, const float* bias, vo
     MAD_REQUIRE(B > 0 && H > 0 && W > 0, "mad_conv_in: bad shape");
     const size_t M = (size_t)B * H * W;
     hipStream_t st = (hipStream_t)stream;
-    if (H % 8 == 0 && W % 16 == 0 && Cout % 32 == 0 && !getenv("MAD_CONV_IN_DIRECT")) {
+    MAD_REQUIRE(!stats || conv_in_mfma_ok(dtype, H, W, Cout),
+                "mad_conv_in_stats: H=%d W=%d Cout=%d is outside the tiled form (H %% 8, W %% 16, Cout in 32..256)", H, W,
+                Cout);
+    if (conv_in_mfma_ok(dtype, H, W, Cout) && (stats || !getenv("MAD_CONV_IN_DIRECT"))) {
         // matrix-pipe form; tiles are walked with a grid stride so the weights are staged once per workgroup
         const int ntiles = B * (H / 8) * (W / 16);
         const dim3 grid((unsigned)std::min(ntiles, 2048));
         const size_t esz = dtype == MAD_BF16 ? 2 : 4;
-        const size_t lds_m = ((size_t)Cout * 29 + 544) * sizeof(float) + (size_t)4 * 32 * Cout * esz;
+        const size_t lds_m = ((size_t)Cout * 29 + 544) * sizeof(float) + (size_t)4 * 32 * Cout * esz + (size_t)8 * Cout * 4;
 #define MAD_CONV_IN_CASE(TN_)                                                                                     \
     case TN_:                                                                                                     \
         if (dtype == MAD_BF16) {                                                                                  \
@@ -717,16 +761,16 @@ extern "C" int mad_conv_in(const float* x, const float* w, const float* bias, vo
             if (!set_b) { hipFuncSetAttribute((const void*)conv_in_mfma_kernel<bf16_t, TN_>,                      \
                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set_b = true; } \
             hipLaunchKernelGGL((conv_in_mfma_kernel<bf16_t, TN_>), grid, dim3(256), lds_m, st, x, w, bias,        \
-                               (bf16_t*)y, B, H, W);                                                              \
+                               (bf16_t*)y, stats, B, H, W);                                                       \
         } else {                                                                                                  \
             static bool set_f = false;                                                                            \
             if (!set_f) { hipFuncSetAttribute((const void*)conv_in_mfma_kernel<float, TN_>,                       \
                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set_f = true; } \
             hipLaunchKernelGGL((conv_in_mfma_kernel<float, TN_>), grid, dim3(256), lds_m, st, x, w, bias,         \
-                               (float*)y, B, H, W);                                                               \
+                               (float*)y, stats, B, H, W);                                                        \
         }                                                                                                         \
         return check_launch("mad_conv_in");
-        switch (lds_m <= 160 * 1024 ? Cout / 32 : 0) {
+        switch (Cout / 32) {
             MAD_CONV_IN_CASE(1) MAD_CONV_IN_CASE(2) MAD_CONV_IN_CASE(3) MAD_CONV_IN_CASE(4)
             MAD_CONV_IN_CASE(6) MAD_CONV_IN_CASE(8)
             default: break;                  // other widths take the direct kernel below
@@ -742,6 +786,21 @@ extern "C" int mad_conv_in(const float* x, const float* w, const float* bias, vo
         hipLaunchKernelGGL((conv_in_kernel<float, 3>), grid, dim3(256), lds, st, x, w, bias,
                            (float*)y, B, H, W, Cout);
     return check_launch("mad_conv_in");
+}
+
+extern "C" int mad_conv_in(const float* x, const float* w, const float* bias, void* y, int dtype, int B, int Cin,
+                           int H, int W, int Cout, void* stream) {
+    return conv_in_impl(x, w, bias, y, nullptr, dtype, B, Cin, H, W, Cout, stream);
+}
+
+extern "C" int mad_conv_in_stats_ok(int dtype, int H, int W, int Cout) {
+    return (dtype == MAD_BF16 || dtype == MAD_F32) && H > 0 && W > 0 && Cout > 0 && conv_in_mfma_ok(dtype, H, W, Cout);
+}
+
+extern "C" int mad_conv_in_stats(const float* x, const float* w, const float* bias, void* y, float* stats, int dtype,
+                                 int B, int Cin, int H, int W, int Cout, void* stream) {
+    MAD_REQUIRE(stats, "mad_conv_in_stats: null statistics pointer");
+    return conv_in_impl(x, w, bias, y, stats, dtype, B, Cin, H, W, Cout, stream);
 }
 
 extern "C" int mad_conv_out(const void* x, int dtype, const float* w, const float* bias, float* y, int B, int Cin,

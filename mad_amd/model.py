@@ -312,7 +312,7 @@ class DhariwalUNet(nn.Module):
         if taps is not None:
             taps["emb"] = emb
 
-        h = _Act(ops.conv_in(x, P["in.w"], P["in.b"], dt))
+        h = _Act(*ops.conv_in(x, P["in.w"], P["in.b"], dt, want_stats=True))
         skips = [h]
         if taps is not None:
             taps[s.enc_conv_name] = h.t

@@ -190,14 +190,25 @@ def linear_f32(x: Tensor, W: Tensor, bias: Optional[Tensor] = None, act_in: bool
 
 
 # ------------------------------------------------------------------------------ convolutions
-def conv_in(x: Tensor, w: Tensor, bias: Tensor, dtype: torch.dtype) -> Tensor:
-    """x NCHW fp32 -> NHWC `dtype`; w (Cout,Cin,3,3) fp32."""
+def conv_in(x: Tensor, w: Tensor, bias: Tensor, dtype: torch.dtype, want_stats: bool = False):
+    """x NCHW fp32 -> NHWC `dtype`; w (Cout,Cin,3,3) fp32.  With ``want_stats`` returns ``(y, part)``: the
+    output's GroupNorm partial sums (B, (H/8)*(W/16), Cout, 2) from the epilogue, or None for a shape the tiled
+    kernel does not cover."""
     _dev(x, w, bias)
     B, Cin, H, W_ = x.shape
     Cout = w.shape[0]
     if x.dtype != torch.float32 or w.dtype != torch.float32 or tuple(w.shape) != (Cout, Cin, 3, 3):
         raise ValueError("conv_in needs fp32 NCHW input and (Cout,Cin,3,3) fp32 weights")
     y = torch.empty((B, H, W_, Cout), dtype=dtype, device=x.device)
+    if want_stats:
+        if not lib.mad_conv_in_stats_ok(_dtype_code(y), H, W_, Cout):
+            check(lib.mad_conv_in(_ptr(x), _ptr(w), _ptr(bias), _ptr(y), _dtype_code(y), B, Cin, H, W_, Cout,
+                                  _stream()), "mad_conv_in")
+            return y, None
+        part = torch.empty((B, (H // 8) * (W_ // 16), Cout, 2), dtype=torch.float32, device=x.device)
+        check(lib.mad_conv_in_stats(_ptr(x), _ptr(w), _ptr(bias), _ptr(y), _ptr(part), _dtype_code(y), B, Cin, H, W_,
+                                    Cout, _stream()), "mad_conv_in_stats")
+        return y, part
     check(lib.mad_conv_in(_ptr(x), _ptr(w), _ptr(bias), _ptr(y), _dtype_code(y), B, Cin, H, W_, Cout, _stream()),
           "mad_conv_in")
     return y

@@ -230,6 +230,17 @@ def test_conv_in_out(dev, dt):
         w, b = _rand((cout, 3, 3, 3), 2, 0.2), _rand((cout,), 3)
         y = ops.conv_in(x.to(dev), w.to(dev), b.to(dev), dt)
         assert rel_err(_nchw(y), F.conv2d(x, w, b, padding=1)) < (1e-5 if dt == torch.float32 else 6e-3), (shape, cout)
+        # the same layer with the epilogue's GroupNorm partial sums (per 8x16 tile) where the tiled kernel runs
+        y2, part = ops.conv_in(x.to(dev), w.to(dev), b.to(dev), dt, want_stats=True)
+        assert torch.equal(y2, y)
+        B_, _, H_, W_ = shape
+        if H_ % 8 == 0 and W_ % 16 == 0:
+            tiles = y.float().reshape(B_, H_ // 8, 8, W_ // 16, 16, cout).permute(0, 1, 3, 2, 4, 5).reshape(B_, -1, 128, cout)
+            assert tuple(part.shape) == (B_, (H_ // 8) * (W_ // 16), cout, 2)
+            assert rel_err(part[..., 0].cpu(), tiles.sum(2).cpu()) < 1e-4
+            assert rel_err(part[..., 1].cpu(), (tiles * tiles).sum(2).cpu()) < 1e-4
+        else:
+            assert part is None
     h = _rand((2, 64, 16, 16), 4)
     wo, bo = _rand((3, 64, 3, 3), 5, 0.05), _rand((3,), 6)
     hq = h.to(dt).float()
