@@ -181,6 +181,12 @@ def main():
     images = synthetic_faces(B, R, seed=100 + rank).to(dev)
     maps = torch.stack([synthetic_parsing_map(R, seed=rank * B + i) for i in range(B)]).to(dev)
 
+    def progress(msg):
+        # a line on stderr now and then: the result line on stdout stays the only thing printed there
+        if rank == 0:
+            print(f"[bench {time.time() - T_PROCESS_START:6.1f}s] {msg}", file=sys.stderr, flush=True)
+
+    progress(f"model built ({os.path.basename(args.config)}, batch {B}, {args.workload})")
     eval_count = [0]
     inner = model.forward
     model.graph_replay = bool(args.graph)
@@ -192,6 +198,8 @@ def main():
         ops.TIMER.active = sample
         sampled[0] += int(sample)
         eval_count[0] += 1
+        if eval_count[0] % 500 == 0:
+            progress(f"{eval_count[0]} denoiser evaluations")
         if sample:
             model.graph_replay = False
         out = inner(*a, **k)
@@ -239,6 +247,7 @@ def main():
         torch.cuda.synchronize()
         if i > 0 or args.warmup == 1:
             per_eval = (time.perf_counter() - tw) / (2 * s_warm - 1)
+        progress(f"warm-up {i + 1}/{args.warmup} done")
     # ---- how many full steps fit the budget (a cap on --steps; every rank must run the same number)
     steps = max(1, args.steps)
     budget = args.time_budget
@@ -255,8 +264,10 @@ def main():
     barrier()
     timed[0] = True
     t0 = time.perf_counter()
-    for _ in range(steps):
+    progress(f"timing {steps} step(s) of {2 * S - 1} evaluations (asked for {args.steps}, budget {budget:.0f} s)")
+    for i_step in range(steps):
         out = one_step()
+        progress(f"step {i_step + 1}/{steps} issued")
     barrier()
     elapsed = time.perf_counter() - t0
     timed[0] = False
@@ -317,8 +328,10 @@ def main():
                          "avg_launch_ms": conv["ms"] / conv["launches"] if conv["launches"] else None,
                          "mfma_kernels": per_kernel},
         }
+        progress("timed region done; bandwidth-bound kernels")
         line["hbm_kernels"] = hbm_kernels(dev, B, R, spec.model_channels)
         if not args.no_cpu_baseline and world == 1:
+            progress(f"CPU baseline ({args.cpu_evals} evaluations of the oracle)")
             line["cpu_baseline"] = cpu_baseline(cfg, spec, S, args.cpu_evals)
         print(json.dumps(line), flush=True)
     if world > 1:
