@@ -11,7 +11,11 @@
 // added in the epilogue (fp32 tile -> LDS -> 16-byte stores with bias and residual, plus the per-image
 // sum / sum of squares for the next GroupNorm).
 //
-// LDS image of a slab: [K-tile][pixel 0..103][128 bytes], chunk index XOR ((pixel>>1)&7).
+// LDS image of a slab: [K-tile][pixel 0..103][128 bytes], chunk index XOR swz(hy, hx) of the halo pixel
+// (hy, hx), swz = (hy + 4*(hx>>1)) & 7.  A fragment read touches 32 output pixels = four 8-pixel runs of four
+// 10-pixel halo rows, shifted by the tap; with this function the sixteen lanes that a ds_read_b128 serves in
+// one LDS cycle always fall on sixteen different 16-byte bank groups, for all nine taps (the plain
+// (pixel>>1)&7 of a dense row-major tile repeats after 16 pixels and collides across the row jumps).
 #include "mma.h"
 
 namespace mad {
@@ -35,6 +39,7 @@ constexpr int OFF_CTAB = OFF_WT + NST * 2 * WT_BYTES;
 constexpr int CTAB_BYTES = SLAB_KT * 512;               // slab channels x (a, d) fp32
 constexpr int LDS_BYTES = OFF_CTAB + CTAB_BYTES;
 constexpr int CLD = BN + 4;                             // fp32 tile row pitch in the epilogue
+__device__ __forceinline__ int swz(int hy, int hx) { return (hy + 4 * (hx >> 1)) & 7; }
 static_assert(LDS_BYTES <= 160 * 1024, "one workgroup's LDS");
 static_assert(2 * 64 * CLD * 4 <= OFF_WT, "the two partial tiles of the epilogue reuse the slab");
 }  // namespace i8
@@ -69,7 +74,7 @@ __global__ __launch_bounds__(512) void conv3x3_img8_kernel(Img8Args a) {
             const int p = blk * 8 + lrow;
             const int hy = p / HP, hx = p - hy * HP;
             const bool ok = p < NPIX && hy >= 1 && hy <= 8 && hx >= 1 && hx <= 8;
-            const int lchunk = pchunk ^ ((p >> 1) & 7);
+            const int lchunk = pchunk ^ swz(hy, hx);
             const T* g = src + ((size_t)(b * 8 + ((hy - 1) & 7)) * 8 + ((hx - 1) & 7)) * cs + coff + lchunk * VEC;
             glds16(ok ? (const void*)g : (const void*)g_zero_page,
                    __builtin_amdgcn_readfirstlane(a_base + k * KT_BYTES + blk * 8 * ROWB));
@@ -88,7 +93,7 @@ __global__ __launch_bounds__(512) void conv3x3_img8_kernel(Img8Args a) {
         for (int it = tid; it < nkt * 64 * 8; it += NTHREADS) {
             const int k = it >> 9, rem = it & 511, px = rem >> 3, ch = rem & 7;
             const int p = (1 + (px >> 3)) * HP + 1 + (px & 7);
-            unsigned char* addr = smem + k * KT_BYTES + p * ROWB + ((ch ^ ((p >> 1) & 7)) << 4);
+            unsigned char* addr = smem + k * KT_BYTES + p * ROWB + ((ch ^ swz(1 + (px >> 3), 1 + (px & 7))) << 4);
             Vec16<T> v; v.raw = *reinterpret_cast<const uint4*>(addr);
             const float* cf = ctab + (k * CK + ch * VEC) * 2;
             float f[VEC]; v.unpack(f);
@@ -162,7 +167,7 @@ __global__ __launch_bounds__(512) void conv3x3_img8_kernel(Img8Args a) {
             const int ky = rd_tap / 3, kx = rd_tap - ky * 3;
             const int p = pbase + ky * HP + kx;
             const unsigned char* arow = smem + rd_k * KT_BYTES + p * ROWB;
-            const int asw = (p >> 1) & 7;
+            const int asw = swz((prow >> 3) + ky, (prow & 7) + kx);
             const unsigned char* wrow = wt0 + rd_slot * WT_BYTES + brow * ROWB;
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
