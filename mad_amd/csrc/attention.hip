@@ -206,11 +206,7 @@ constexpr int KT2 = 64;
 #endif
 constexpr float RESCALE_THR = MAD_ATTN_THR;
 
-__device__ __forceinline__ float max3f(float a, float b, float c) {
-    float r;
-    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
+__device__ __forceinline__ float max3f(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
 
 template <int NW>
 __global__ __launch_bounds__(NW * 64) void attention_bf16_kernel(const bf16_t* __restrict__ qkv,

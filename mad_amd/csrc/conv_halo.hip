@@ -77,6 +77,27 @@ __device__ unsigned g_stamps[8 * 9 * 8];
 #define MAD_STAMP_PHASE(k)
 #endif
 
+// fma1 is an asm statement: use it only on operands that come from ordinary vector instructions, LDS reads or
+// scalars (never straight from v_exp / v_rcp or an MFMA: see div2)
+__device__ __forceinline__ float fma1(float a, float b, float c) {
+    float r;
+    asm("v_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+// t0 /= u0, t1 /= u1 as reciprocal + product, four one-element instructions in one statement.  On this chip a
+// result of the transcendental unit needs one wait state before an ordinary vector instruction reads it; the
+// compiler inserts it for its own instructions but not inside or in front of an asm statement, so the order
+// below provides it: each product is separated from its reciprocal by one other instruction.
+__device__ __forceinline__ void div2(float& t0, float& t1, float u0, float u1) {
+    float r0, r1;
+    asm("v_rcp_f32 %0, %4\n\t"
+        "v_rcp_f32 %1, %5\n\t"
+        "v_mul_f32 %2, %2, %0\n\t"
+        "v_mul_f32 %3, %3, %1"
+        : "=&v"(r0), "=&v"(r1), "+v"(t0), "+v"(t1)
+        : "v"(u0), "v"(u1));
+}
+
 template <int BN, int TW> constexpr int halo_lds_bytes() {
     constexpr int stage = 2 * halo_buf<TW>() + NWBUF * BN * HROW + 2 * CTAB_BYTES + 1024;   // + one sink KiB
     constexpr int epi = 128 * (BN + 4) * 4;
@@ -239,14 +260,17 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / (TW / 16) / 2) void conv3x3
             else { f0 = __uint_as_float(w[2 * pr]); f1 = __uint_as_float(w[2 * pr + 1]); }
             const float4 ad = xcf[pr & 1];
             if (pr + 1 < XPAIRS) xcf[(pr + 1) & 1] = *reinterpret_cast<const float4*>(xcoef + 4 * (pr + 1));
-            xt[0] = fmaf(f0, ad.x, ad.y); xt[1] = fmaf(f1, ad.z, ad.w);
+            // one-element instructions on purpose (fma1 / div2): left to itself the compiler pairs these into
+            // v_pk_fma_f32 / v_pk_mul_f32, which needs three register moves per pair to line up (a0, a1) and
+            // (d0, d1) from the interleaved table and, issued beside MFMAs, costs more than the two plain ones
+            xt[0] = fma1(f0, ad.x, ad.y); xt[1] = fma1(f1, ad.z, ad.w);
             // exponent of the sigmoid: -t*log2(e) with the activation, -200 without it (exp2 gives 0, the
             // reciprocal 1, the product t itself): no select on the way
-            xu[0] = fmaf(xt[0], xk1, xk0); xu[1] = fmaf(xt[1], xk1, xk0);
+            xu[0] = fma1(xt[0], xk1, xk0); xu[1] = fma1(xt[1], xk1, xk0);
         } else if (k == 1) {
             xu[0] = 1.0f + __builtin_amdgcn_exp2f(xu[0]); xu[1] = 1.0f + __builtin_amdgcn_exp2f(xu[1]);
         } else if (k == 2) {
-            xt[0] *= __builtin_amdgcn_rcpf(xu[0]); xt[1] *= __builtin_amdgcn_rcpf(xu[1]);
+            div2(xt[0], xt[1], xu[0], xu[1]);
         } else {
             if (sizeof(T) == 2) {
                 typedef float f32x2_t __attribute__((ext_vector_type(2)));
