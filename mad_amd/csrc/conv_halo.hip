@@ -211,6 +211,9 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / (TW / 16) / 2) void conv3x3
         glds16s(a.coef + ((size_t)b * Ctot + cc * CK) * 2, (unsigned)(lane & (LANES - 1)) * 16u,
                 __builtin_amdgcn_readfirstlane(ctab_base + buf * CTAB_BYTES));
     };
+    // exponent of the sigmoid: -t*log2(e) with the activation, -200 without it (exp2 gives 0, the reciprocal
+    // 1, the product t itself): no select on the way
+    const float xk1 = a.act ? -1.44269504088896340736f : 0.0f, xk0 = a.act ? 0.0f : -200.0f;
     // in-place y = act(x*a + d) of this thread's item j in halo buffer `buf` (zeros for padding)
     auto xform_item = [&](int j, int buf) {
         if (!FUSE) return;
@@ -224,9 +227,12 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / (TW / 16) / 2) void conv3x3
 #pragma unroll
         for (int i = 0; i < VEC; i += 2) {
             const float4 ad = *reinterpret_cast<const float4*>(cf + 2 * i);
-            const float t0 = fmaf(f[i], ad.x, ad.y), t1 = fmaf(f[i + 1], ad.z, ad.w);
-            f[i] = a.act ? silu_f(t0) : t0;
-            f[i + 1] = a.act ? silu_f(t1) : t1;
+            // one-element instructions, as in the in-loop form below (no packed pairs, no register shuffles)
+            float t0 = fma1(f[i], ad.x, ad.y), t1 = fma1(f[i + 1], ad.z, ad.w);
+            const float u0 = 1.0f + __builtin_amdgcn_exp2f(fma1(t0, xk1, xk0));
+            const float u1 = 1.0f + __builtin_amdgcn_exp2f(fma1(t1, xk1, xk0));
+            div2(t0, t1, u0, u1);
+            f[i] = t0; f[i + 1] = t1;
         }
         v.pack(f);
         if ((padmask >> j) & 1) v.raw = make_uint4(0, 0, 0, 0);
@@ -240,7 +246,6 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / (TW / 16) / 2) void conv3x3
     // the first coefficient pair are requested at the top of the tap; each later coefficient pair one pair ahead.
     constexpr int XPAIRS = VEC / 2, XSTRIDE = 16 / XPAIRS;
     uint4 xraw; float4 xcf[2]; float xt[2], xu[2]; unsigned xout[4];
-    const float xk1 = a.act ? -1.44269504088896340736f : 0.0f, xk0 = a.act ? 0.0f : -200.0f;
     const unsigned char* xaddr = nullptr; const float* xcoef = nullptr;
     auto xf_begin = [&](int j, int buf) {
         const int item = tid + NT * j;
