@@ -455,8 +455,23 @@ __global__ __launch_bounds__(256) void conv_in_kernel(const float* __restrict__ 
     }
 }
 
-// First layer on the fp32 matrix pipe (v_mfma_f32_32x32x2_f32, K = 27 padded to 28), same arithmetic
-// type for both activation dtypes.  A workgroup walks 16x8-pixel tiles with a grid stride; the
+// (hi, lo) bf16 pairs of two floats: x = hi + lo up to 2^-17 |x| (lo = the rounded remainder of the rounded x)
+__device__ __forceinline__ void split_bf16x2(float a, float b, unsigned& hi, unsigned& lo) {
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    const f32x2_t v = {a, b};
+    hi = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+    const f32x2_t r = {a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xffff0000u)};
+    lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2_t));
+}
+
+// First layer.  fp32 activations: the fp32 matrix pipe (v_mfma_f32_32x32x2_f32, K = 27 padded to 28).  bf16
+// activations: the image and the weights are both fp32, and on the fp32 pipe (1/16 of the bf16 rate) the layer
+// would be bound by it (14.5 GFLOP at 256x256, batch 32: 92 us at best); instead both operands are split into
+// bf16 (hi, lo) pairs and the product is taken as hi*hi + hi*lo + lo*hi on the bf16 pipe with fp32
+// accumulation (K = 27 padded to 32: 24 instead of 56 four-times-longer instructions per tile).  What is
+// dropped is lo*lo and the third-order remainders, 2^-16 of the product against the 2^-9 of the bf16 rounding
+// of the result.  A workgroup walks 16x8-pixel tiles with a grid stride; the
 // weights ([Cout][29] fp32, odd pitch = conflict-free operand reads) are loaded to LDS once per
 // workgroup.  Per tile: the 3 x 10 x 18 input halo goes to LDS; each wave owns two tile rows (32
 // pixels) x all Cout channels, reads its A operand straight from the halo at the tap's offset, and
@@ -473,13 +488,27 @@ __global__ __launch_bounds__(256) void conv_in_mfma_kernel(const float* __restri
     constexpr int HALO_N = 3 * 10 * 18;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_m[];
     float* wl = reinterpret_cast<float*>(smem_m);                  // [Cout][WP]
-    float* halo = wl + Cout * WP;                                  // [3][10][18]
+    float* halo = wl + Cout * 32;                                  // [3][10][18]; the weight region holds Cout x 128 bytes
     T* oslab = reinterpret_cast<T*>(halo + ((HALO_N + 3) & ~3));   // [4 waves][32][Cout]
     float* red = reinterpret_cast<float*>(oslab + 4 * 32 * Cout);  // [4 waves][Cout][2]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int i = tid; i < Cout * WP; i += 256) {
-        const int n = i / WP, k = i - n * WP;
-        wl[i] = k < 27 ? w[n * 27 + k] : 0.0f;
+    if constexpr (sizeof(T) == 2) {
+        // bf16 form: the weights as (hi, lo) bf16 pairs, [hi | lo][k half st][channel][32 bytes = k 16 st .. + 15]
+        // (k >= 27: zero): a lane's B fragment is one 16-byte read, lanes of a wave cover 2 KiB contiguously
+        unsigned* wq = reinterpret_cast<unsigned*>(smem_m);
+        for (int i = tid; i < Cout * 16; i += 256) {      // one k pair each
+            const int n = i >> 4, kp = i & 15, k = 2 * kp;
+            unsigned hi, lo;
+            split_bf16x2(k < 27 ? w[n * 27 + k] : 0.0f, k + 1 < 27 ? w[n * 27 + k + 1] : 0.0f, hi, lo);
+            const int st = kp >> 3, word = kp & 7;
+            wq[((0 * 2 + st) * Cout + n) * 8 + word] = hi;
+            wq[((1 * 2 + st) * Cout + n) * 8 + word] = lo;
+        }
+    } else {
+        for (int i = tid; i < Cout * WP; i += 256) {
+            const int n = i / WP, k = i - n * WP;
+            wl[i] = k < 27 ? w[n * 27 + k] : 0.0f;
+        }
     }
     const int row = lane & 31, kh = lane >> 5;
     const int pixoff = (wave * 2 + (row >> 4)) * 18 + (row & 15);
@@ -493,6 +522,17 @@ __global__ __launch_bounds__(256) void conv_in_mfma_kernel(const float* __restri
     float bcol[TN];
 #pragma unroll
     for (int jn = 0; jn < TN; ++jn) bcol[jn] = bias[jn * 32 + row];
+    // bf16 form: halo offsets of this lane's sixteen k = 16 st + 8 kh + j (k >= 27 meets a zero weight: any finite
+    // halo value will do)
+    int koff16[sizeof(T) == 2 ? 16 : 1];
+    if constexpr (sizeof(T) == 2) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int k = 16 * (i >> 3) + 8 * kh + (i & 7);
+            const int c = k / 9, r = k - c * 9, ky = r / 3, kx = r - ky * 3;
+            koff16[i] = k < 27 ? c * 180 + ky * 18 + kx : 0;
+        }
+    }
     const int tiles_x = W / 16, tiles_y = H / 8;
     const int ntiles = B * tiles_x * tiles_y;
     T* const my_slab = oslab + wave * 32 * Cout;
@@ -518,6 +558,26 @@ __global__ __launch_bounds__(256) void conv_in_mfma_kernel(const float* __restri
         for (int jn = 0; jn < TN; ++jn)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[jn][e] = bcol[jn];
+        if constexpr (sizeof(T) == 2) {
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                uint4 ah, al;            // this lane's pixel, k = 16 st + 8 kh .. + 7, as (hi, lo) bf16
+                unsigned* ahp = reinterpret_cast<unsigned*>(&ah);
+                unsigned* alp = reinterpret_cast<unsigned*>(&al);
+#pragma unroll
+                for (int j = 0; j < 8; j += 2)
+                    split_bf16x2(halo[pixoff + koff16[st * 8 + j]], halo[pixoff + koff16[st * 8 + j + 1]], ahp[j / 2], alp[j / 2]);
+                const unsigned char* wq = smem_m;
+#pragma unroll
+                for (int jn = 0; jn < TN; ++jn) {
+                    const uint4 wh = *reinterpret_cast<const uint4*>(wq + (((0 * 2 + st) * Cout + jn * 32 + row) * 8 + kh * 4) * 4);
+                    const uint4 wlo = *reinterpret_cast<const uint4*>(wq + (((1 * 2 + st) * Cout + jn * 32 + row) * 8 + kh * 4) * 4);
+                    mma_chunk<bf16_t>(acc[jn], ah, wh);
+                    mma_chunk<bf16_t>(acc[jn], ah, wlo);
+                    mma_chunk<bf16_t>(acc[jn], al, wh);
+                }
+            }
+        } else {
 #pragma unroll
         for (int s2 = 0; s2 < 14; ++s2) {
             const float av = halo[pixoff + koff[s2]];
@@ -526,6 +586,7 @@ __global__ __launch_bounds__(256) void conv_in_mfma_kernel(const float* __restri
                 const float bv = wl[(jn * 32 + row) * WP + 2 * s2 + kh];
                 acc[jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[jn], 0, 0, 0);
             }
+        }
         }
         // accumulators -> wave-private slab (pixel-major) -> 16-byte global stores
 #pragma unroll
@@ -730,7 +791,7 @@ extern "C" int mad_conv2d_ws(const void* x1, int C1, const void* x2, int C2, con
 // Shapes the matrix-pipe form of the first layer covers (the only form that can take statistics).
 static bool conv_in_mfma_ok(int dtype, int H, int W, int Cout) {
     const size_t esz = dtype == MAD_BF16 ? 2 : 4;
-    const size_t lds_m = ((size_t)Cout * 29 + 544) * sizeof(float) + (size_t)4 * 32 * Cout * esz + (size_t)8 * Cout * 4;
+    const size_t lds_m = ((size_t)Cout * 32 + 544) * sizeof(float) + (size_t)4 * 32 * Cout * esz + (size_t)8 * Cout * 4;
     const int tn = Cout / 32;
     return H % 8 == 0 && W % 16 == 0 && Cout % 32 == 0 && lds_m <= 160 * 1024 &&
            (tn == 1 || tn == 2 || tn == 3 || tn == 4 || tn == 6 || tn == 8);
@@ -753,7 +814,7 @@ static int conv_in_impl(const float* x, const float* w, const float* bias, void*
         const int ntiles = B * (H / 8) * (W / 16);
         const dim3 grid((unsigned)std::min(ntiles, 2048));
         const size_t esz = dtype == MAD_BF16 ? 2 : 4;
-        const size_t lds_m = ((size_t)Cout * 29 + 544) * sizeof(float) + (size_t)4 * 32 * Cout * esz + (size_t)8 * Cout * 4;
+        const size_t lds_m = ((size_t)Cout * 32 + 544) * sizeof(float) + (size_t)4 * 32 * Cout * esz + (size_t)8 * Cout * 4;
 #define MAD_CONV_IN_CASE(TN_)                                                                                     \
     case TN_:                                                                                                     \
         if (dtype == MAD_BF16) {                                                                                  \
