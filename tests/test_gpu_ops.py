@@ -85,7 +85,9 @@ def test_sampler_golden(dev, kind):
             s.config.prediction_type = "epsilon"
             cmp(s.add_noise(T("orig"), T("noise"), torch.tensor([t])), f"{key}/add_noise")
     print(f"{kind}: {n_exact}/{n_total} sampler goldens bit-exact")
-    assert n_exact >= 0.4 * n_total      # the rest differ by a 1-ulp host coefficient (see cmp)
+    # measured on the MI355X boxes: 53/95 (DDPM), 61/113 (DDIM) identical to the last bit; the rest differ by a
+    # 1-ulp host coefficient (see cmp) and stay inside its 4e-7 bound
+    assert n_exact >= 0.5 * n_total
 
 
 def test_sampler_errors(dev):
