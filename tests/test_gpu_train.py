@@ -144,6 +144,21 @@ def test_training_reduces_loss(dev):
     assert float((tr.ema - tr.flat).abs().max()) > 0
 
 
+def test_accumulated_micro_batches_draw_their_own_dropout_masks(dev):
+    """The same micro-batch twice inside one optimizer step: with dropout on the two passes must see different
+    masks (the reference draws a fresh mask per forward, main.py:239-246), so their losses differ; with the
+    position inside the step held fixed the pass is reproducible to the last bit."""
+    from mad_amd.train import UNetTrainer
+    cfg, m, sd, x, t, lab, target = _setup("model_tiny.yaml", "fp32", dev, B=2)
+    tr = UNetTrainer(m.unet, lr=1e-4, dropout=0.3)
+    args = (x.to(dev), t.to(dev), lab.to(dev), target.to(dev))
+    first = float(tr.forward_backward(*args))
+    again = float(tr.forward_backward(*args))                    # not accumulating: position 0 both times
+    second = float(tr.forward_backward(*args, accumulate=True))  # position 1 of the same step
+    assert again == first
+    assert abs(second - first) > 1e-6 * abs(first)
+
+
 @pytest.mark.parametrize("cfg_file,precision", [("model_tiny.yaml", "fp32"), ("model_tiny.yaml", "bf16"),
                                                 ("model_64_64.yaml", "bf16")])
 def test_refreshed_working_copies_equal_a_fresh_pack(dev, cfg_file, precision):
