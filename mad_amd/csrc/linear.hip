@@ -126,7 +126,11 @@ extern "C" int mad_linear_f32(const float* x, const float* W, const float* bias,
     MAD_REQUIRE(K <= 4096, "mad_linear_f32: K=%d exceeds the staged-row limit 4096", K);
     const int groups = (N + LIN_FT - 1) / LIN_FT;
     const int grid = std::max(1, std::min((groups + 15) / 16, 512));   // ~4 feature groups per wave
-    if ((size_t)32 * K * sizeof(float) <= 128 * 1024) {
+    if (rows <= 4) {
+        // one timestep and one label for the whole batch (the sampling loops): a single row, broadcast by the caller
+        hipLaunchKernelGGL(linear_kernel<4>, dim3(grid), dim3(256), (size_t)4 * K * sizeof(float),
+                           (hipStream_t)stream, x, W, bias, y, rows, K, N, act_in, act_out, accumulate);
+    } else if ((size_t)32 * K * sizeof(float) <= 128 * 1024) {
         const size_t lds = (size_t)32 * K * sizeof(float);
         static int lds_dev = -1;
         MAD_REQUIRE(raise_lds_limit((const void*)linear_kernel<32>, 128 * 1024, &lds_dev),

@@ -291,16 +291,23 @@ class DhariwalUNet(nn.Module):
         t = noise_labels.to(device=x.device, dtype=torch.float32).reshape(-1).contiguous()
         if t.numel() not in (1, B):
             raise ValueError(f"noise_labels must have 1 or {B} entries, got {t.numel()}")
-        # embedding MLP (model.py:564-576)
-        emb = ops.pos_embedding(t, P["freqs"], B)
+        # embedding MLP (model.py:564-576).  One timestep and one label row for the whole batch (what the sampling
+        # loops pass: `process_label` repeats one class, the loops one timestep) need the embedding once: it is
+        # computed as a single row and the per-block affines are read with a row stride of zero.
+        uniform = t.numel() == 1 and (not s.label_dim or class_labels is None or class_labels.shape[0] == 1
+                                      or getattr(class_labels, "mad_uniform_rows", False))
+        rows_e = 1 if uniform else B
+        emb = ops.pos_embedding(t, P["freqs"], rows_e)
         emb = ops.linear_f32(emb, P["map_layer0.weight"], P["map_layer0.bias"], act_out=True)
         if s.label_dim:
             if class_labels is None:
                 class_labels = torch.zeros((1, s.label_dim), device=x.device)
             lab = class_labels.to(device=x.device, dtype=torch.float32).reshape(-1, s.label_dim)
-            if lab.shape[0] == 1 and B > 1:
+            if uniform:
+                lab = lab[:1]
+            elif lab.shape[0] == 1 and B > 1:
                 lab = lab.expand(B, -1)
-            if lab.shape[0] != B:
+            if lab.shape[0] != rows_e:
                 raise ValueError(f"class_labels must have 1 or {B} rows, got {lab.shape[0]}")
             emb = ops.linear_f32(emb, P["map_layer1.weight"], P["map_layer1.bias"])
             emb = ops.linear_f32(lab.contiguous(), P["map_label.weight"], None, out=emb, accumulate=True,
@@ -308,7 +315,7 @@ class DhariwalUNet(nn.Module):
         else:
             emb = ops.linear_f32(emb, P["map_layer1.weight"], P["map_layer1.bias"], act_out=True)
         ada = ops.linear_f32(emb, P["aff.w"], P["aff.b"])          # every block's affine at once
-        total = P["aff.total"]
+        total = P["aff.total"] if rows_e > 1 else 0                # row stride of `ada` as the kernels read it
         if taps is not None:
             taps["emb"] = emb
 

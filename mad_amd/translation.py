@@ -126,6 +126,7 @@ class TranslationDiffusion:
         if label is not None and isinstance(label, int):
             label = torch.nn.functional.one_hot(torch.tensor(label), self.num_classes).float()
             label = label.unsqueeze(0).repeat(batch_size, 1).to(self.device)
+            label.mad_uniform_rows = True      # every row is the same class: the denoiser embeds it once
         return label
 
     def sample_xt(self, input_: Tensor, timesteps, mask: Optional[Tensor] = None) -> Tensor:

@@ -414,3 +414,32 @@ def test_graph_replay_matches_eager(dev):
     want = m(x, t, class_labels=lab)
     m.graph_replay = True
     assert torch.equal(m(x, t, class_labels=lab), want)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_uniform_label_rows_take_the_single_row_embedding(dev, precision):
+    """`process_label` marks its repeated one-hot rows; the denoiser then embeds (timestep, class) once and reads the
+    per-block affines with a zero row stride.  Same output as the row-per-sample path."""
+    from mad_amd.config import load_cfg
+    from mad_amd.model import build_model
+    cfg = load_cfg(os.path.join(REPO, "configs", "model_tiny.yaml"))
+    m = build_model(cfg, precision=precision)
+    m.unet.init_seeded(4)
+    m = m.to(dev).eval()
+    R = m.spec.img_resolution
+    x = torch.randn(3, 3, R, R, generator=torch.Generator().manual_seed(5)).to(dev)
+    t = torch.tensor([417.0], device=dev)
+    lab = torch.tensor([[0.0, 1.0]]).repeat(3, 1).to(dev)
+    per_row = m(x, t, class_labels=lab)
+    marked = lab.clone()
+    marked.mad_uniform_rows = True
+    once = m(x, t, class_labels=marked)
+    one_row = m(x, t, class_labels=lab[:1])
+    tol = 1e-5 if precision == "fp32" else 2e-2
+    assert rel_err(once.float().cpu(), per_row.float().cpu()) < tol
+    assert torch.equal(once, one_row)
+    # different timesteps per sample can not share an embedding: the mark is ignored
+    t3 = torch.tensor([417.0, 12.0, 900.0], device=dev)
+    a = m(x, t3, class_labels=marked)
+    b = m(x, t3, class_labels=lab)
+    assert torch.equal(a, b)
