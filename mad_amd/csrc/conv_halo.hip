@@ -133,7 +133,9 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / (TW / 16) / 2) void conv3x3
     unsigned char* const ctab0 = wt0 + NWBUF * WTILE_BYTES;
     unsigned char* const sink0 = ctab0 + 2 * CTAB_BYTES;     // target of copies that only keep op counts equal
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // the wave index is read into a scalar register: LDS destinations of the copies and everything else derived
+    // from it then live in scalar registers and cost no vector instructions
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
 
     // ---- tile coordinates (XCD-aware order: consecutive logical tiles share an L2)
@@ -183,6 +185,24 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / (TW / 16) / 2) void conv3x3
         if (!ok) padmask |= 1u << j;
         lchunks |= (unsigned)((tid & 3) ^ ((hx >> 1) & 3)) << (2 * j);
     }
+    // The last round of the 16-wide tile holds only LAST_REAL (16) items.  Its transform is not run as one more
+    // whole-item round by every wave: the LAST_REAL * XPAIRS element pairs are spread over the lanes of wave 0, one
+    // pair per lane (a quarter of an item's arithmetic, once).
+    constexpr int XPAIRS = VEC / 2;
+    constexpr int LAST_REAL = HALO_ITEMS - NT * (HALO_ROUNDS - 1);
+    constexpr bool MINI = FUSE && HALO_ROUNDS > 1 && LAST_REAL * XPAIRS <= 64;
+    int mini_off = 0, mini_cf = 0;       // byte offset of this lane's pair in a halo buffer; float offset of its (a, d) pairs
+    bool mini_on = false, mini_pad = false;
+    if constexpr (MINI) {
+        const int it = NT * (HALO_ROUNDS - 1) + lane / XPAIRS, pr = lane % XPAIRS;
+        const int p = it >> 2;
+        const int hy = p / HSX, hx = p - hy * HSX;
+        const int iy = ty0 - 1 + hy, ix = tx0 - 1 + hx;
+        mini_on = wave == 0 && lane < LAST_REAL * XPAIRS;
+        mini_pad = !(iy >= 0 && iy < a.H && ix >= 0 && ix < a.W);
+        mini_off = it * 16 + pr * (16 / XPAIRS);
+        mini_cf = (((it & 3) ^ ((hx >> 1) & 3)) * VEC + 2 * pr) * 2;
+    }
     const unsigned halo_base = lds_addr(halo0);
     const unsigned sink_base = lds_addr(sink0);
     auto dma_item = [&](int cc, int j, int buf) {
@@ -214,29 +234,33 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / (TW / 16) / 2) void conv3x3
     // exponent of the sigmoid: -t*log2(e) with the activation, -200 without it (exp2 gives 0, the reciprocal
     // 1, the product t itself): no select on the way
     const float xk1 = a.act ? -1.44269504088896340736f : 0.0f, xk0 = a.act ? 0.0f : -200.0f;
-    // in-place y = act(x*a + d) of this thread's item j in halo buffer `buf` (zeros for padding)
-    auto xform_item = [&](int j, int buf) {
-        if (!FUSE) return;
-        const int item = tid + NT * j;
-        if (j == HALO_ROUNDS - 1 && item >= HALO_ITEMS) return;     // only the last round is partial
-        unsigned char* addr = halo0 + buf * HALO_BUF + item * 16;
-        Vec16<T> v; v.raw = *reinterpret_cast<const uint4*>(addr);
-        const int lc = (lchunks >> (2 * j)) & 3;
-        const float* cf = reinterpret_cast<const float*>(ctab0 + buf * CTAB_BYTES) + lc * VEC * 2;
-        float f[VEC]; v.unpack(f);
-#pragma unroll
-        for (int i = 0; i < VEC; i += 2) {
-            const float4 ad = *reinterpret_cast<const float4*>(cf + 2 * i);
-            // one-element instructions, as in the in-loop form below (no packed pairs, no register shuffles)
-            float t0 = fma1(f[i], ad.x, ad.y), t1 = fma1(f[i + 1], ad.z, ad.w);
-            const float u0 = 1.0f + __builtin_amdgcn_exp2f(fma1(t0, xk1, xk0));
-            const float u1 = 1.0f + __builtin_amdgcn_exp2f(fma1(t1, xk1, xk0));
-            div2(t0, t1, u0, u1);
-            f[i] = t0; f[i + 1] = t1;
+    // in-place y = act(x*a + d) of this lane's element pair of the last round (MINI), zeros for padding
+    auto xform_mini = [&](int buf) {
+        unsigned char* addr = halo0 + buf * HALO_BUF + mini_off;
+        const float4 ad = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(ctab0 + buf * CTAB_BYTES) + mini_cf);
+        float f0, f1;
+        if (sizeof(T) == 2) {
+            const unsigned w = *reinterpret_cast<const unsigned*>(addr);
+            f0 = __uint_as_float(w << 16); f1 = __uint_as_float(w & 0xffff0000u);
+        } else {
+            const float2 w = *reinterpret_cast<const float2*>(addr);
+            f0 = w.x; f1 = w.y;
         }
-        v.pack(f);
-        if ((padmask >> j) & 1) v.raw = make_uint4(0, 0, 0, 0);
-        *reinterpret_cast<uint4*>(addr) = v.raw;
+        float t0 = fma1(f0, ad.x, ad.y), t1 = fma1(f1, ad.z, ad.w);
+        const float u0 = 1.0f + __builtin_amdgcn_exp2f(fma1(t0, xk1, xk0));
+        const float u1 = 1.0f + __builtin_amdgcn_exp2f(fma1(t1, xk1, xk0));
+        div2(t0, t1, u0, u1);
+        if (mini_pad) { t0 = 0.0f; t1 = 0.0f; }
+        if (mini_on) {
+            if (sizeof(T) == 2) {
+                typedef float f32x2_t __attribute__((ext_vector_type(2)));
+                typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+                const f32x2_t v2 = {t0, t1};
+                *reinterpret_cast<unsigned*>(addr) = __builtin_bit_cast(unsigned, __builtin_convertvector(v2, bf16x2_t));
+            } else {
+                *reinterpret_cast<float2*>(addr) = make_float2(t0, t1);
+            }
+        }
     };
 
     // The same transform cut into 16 short pieces, one behind each MFMA of a tap (in-loop form): the matrix
@@ -244,7 +268,7 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / (TW / 16) / 2) void conv3x3
     // the tap's last MFMA.  Element pair p (one dword of bf16, two floats of fp32) goes through four stages in
     // the slots XSTRIDE*p .. XSTRIDE*p+3: unpack + multiply-add, exp, reciprocal + product, pack.  The item and
     // the first coefficient pair are requested at the top of the tap; each later coefficient pair one pair ahead.
-    constexpr int XPAIRS = VEC / 2, XSTRIDE = 16 / XPAIRS;
+    constexpr int XSTRIDE = 16 / XPAIRS;
     uint4 xraw; float4 xcf[2]; float xt[2], xu[2]; unsigned xout[4];
     const unsigned char* xaddr = nullptr; const float* xcoef = nullptr;
     auto xf_begin = [&](int j, int buf) {
@@ -289,6 +313,41 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / (TW / 16) / 2) void conv3x3
                 const int item = tid + NT * j;
                 if (j < HALO_ROUNDS - 1 || item < HALO_ITEMS)
                     *reinterpret_cast<uint4*>(const_cast<unsigned char*>(xaddr)) = o;
+            }
+        }
+    };
+
+    // The one-pair form of the last round (MINI), stages in slots 0..3
+    auto xm_begin = [&](int buf) {
+        xaddr = halo0 + buf * HALO_BUF + mini_off;
+        if (sizeof(T) == 2) xraw.x = *reinterpret_cast<const unsigned*>(xaddr);
+        else { const uint2 w = *reinterpret_cast<const uint2*>(xaddr); xraw.x = w.x; xraw.y = w.y; }
+        xcf[0] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(ctab0 + buf * CTAB_BYTES) + mini_cf);
+    };
+    auto xm_slot = [&](int k) {
+        if (k == 0) {
+            float f0, f1;
+            if (sizeof(T) == 2) { f0 = __uint_as_float(xraw.x << 16); f1 = __uint_as_float(xraw.x & 0xffff0000u); }
+            else { f0 = __uint_as_float(xraw.x); f1 = __uint_as_float(xraw.y); }
+            const float4 ad = xcf[0];
+            xt[0] = fma1(f0, ad.x, ad.y); xt[1] = fma1(f1, ad.z, ad.w);
+            xu[0] = fma1(xt[0], xk1, xk0); xu[1] = fma1(xt[1], xk1, xk0);
+        } else if (k == 1) {
+            xu[0] = 1.0f + __builtin_amdgcn_exp2f(xu[0]); xu[1] = 1.0f + __builtin_amdgcn_exp2f(xu[1]);
+        } else if (k == 2) {
+            div2(xt[0], xt[1], xu[0], xu[1]);
+        } else if (k == 3) {
+            if (mini_pad) { xt[0] = 0.0f; xt[1] = 0.0f; }
+            if (mini_on) {
+                if (sizeof(T) == 2) {
+                    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+                    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+                    const f32x2_t v2 = {xt[0], xt[1]};
+                    *reinterpret_cast<unsigned*>(const_cast<unsigned char*>(xaddr)) =
+                        __builtin_bit_cast(unsigned, __builtin_convertvector(v2, bf16x2_t));
+                } else {
+                    *reinterpret_cast<float2*>(const_cast<unsigned char*>(xaddr)) = make_float2(xt[0], xt[1]);
+                }
             }
         }
     };
@@ -347,28 +406,43 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / (TW / 16) / 2) void conv3x3
 #pragma unroll
     for (int t = 0; t < PF; ++t) stage_w(0, t, t);
     if (FUSE) {
-        // Copies retire in issue order: item j is transformed as soon as it (and the table, which every
-        // wave copies for itself) has landed, while the later items and the weight tiles are still in flight.
-        static_assert(HALO_ROUNDS - 1 + PF * NW < 64, "vmcnt range");
+        // One wait for the table and the whole halo (the weight tiles, issued last, may still be in flight), then
+        // every item is read before any is rewritten and the coefficient rows of item j+1 are requested before
+        // item j is computed: the items' dependent chains (LDS read, multiply-add, exp, reciprocal, product,
+        // pack, LDS write) overlap instead of running one behind the other.
+        static_assert(PF * NW < 64, "vmcnt range");
+        dma_wait_upto<PF * NW>();
+        constexpr int FULL = MINI ? HALO_ROUNDS - 1 : HALO_ROUNDS;
+        uint4 raw[FULL];
 #pragma unroll
-        for (int j = 0; j < HALO_ROUNDS; ++j) {
-            switch (HALO_ROUNDS - 1 - j + PF * NW) {
-                case 0: dma_wait_upto<0>(); break;
-                case 1: dma_wait_upto<1>(); break;
-                case 2: dma_wait_upto<2>(); break;
-                case 3: dma_wait_upto<3>(); break;
-                case 4: dma_wait_upto<4>(); break;
-                case 5: dma_wait_upto<5>(); break;
-                case 6: dma_wait_upto<6>(); break;
-                case 7: dma_wait_upto<7>(); break;
-                case 8: dma_wait_upto<8>(); break;
-                case 9: dma_wait_upto<9>(); break;
-                case 10: dma_wait_upto<10>(); break;
-                case 11: dma_wait_upto<11>(); break;
-                default: dma_wait_all(); break;
+        for (int j = 0; j < FULL; ++j) raw[j] = *reinterpret_cast<const uint4*>(halo0 + (tid + NT * j) * 16);
+        auto load_cf = [&](int j, float4* out) {
+            const float* cf = reinterpret_cast<const float*>(ctab0) + ((lchunks >> (2 * j)) & 3) * VEC * 2;
+#pragma unroll
+            for (int q = 0; q < XPAIRS; ++q) out[q] = *reinterpret_cast<const float4*>(cf + 4 * q);
+        };
+        float4 cfr[2][XPAIRS];
+        load_cf(0, cfr[0]);
+#pragma unroll
+        for (int j = 0; j < FULL; ++j) {
+            if (j + 1 < FULL) load_cf(j + 1, cfr[(j + 1) & 1]);
+            Vec16<T> v; v.raw = raw[j];
+            float f[VEC]; v.unpack(f);
+#pragma unroll
+            for (int q = 0; q < XPAIRS; ++q) {
+                const float4 ad = cfr[j & 1][q];
+                float t0 = fma1(f[2 * q], ad.x, ad.y), t1 = fma1(f[2 * q + 1], ad.z, ad.w);
+                const float u0 = 1.0f + __builtin_amdgcn_exp2f(fma1(t0, xk1, xk0));
+                const float u1 = 1.0f + __builtin_amdgcn_exp2f(fma1(t1, xk1, xk0));
+                div2(t0, t1, u0, u1);
+                f[2 * q] = t0; f[2 * q + 1] = t1;
             }
-            xform_item(j, 0);
+            v.pack(f);
+            if ((padmask >> j) & 1) v.raw = make_uint4(0, 0, 0, 0);
+            if (j < HALO_ROUNDS - 1 || tid + NT * j < HALO_ITEMS)
+                *reinterpret_cast<uint4*>(halo0 + (tid + NT * j) * 16) = v.raw;
         }
+        if (MINI) xform_mini(0);
     }
     dma_wait_all();
 
@@ -433,7 +507,8 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / (TW / 16) / 2) void conv3x3
                     afs[g & 1][q] = *reinterpret_cast<const uint4*>(halo + a_off[kx][kk] + (2 * (q0 + q) + ky) * HSX * HROW);
             };
             read_group(0);
-            if (do_x) xf_begin(tap - 3, nb);
+            const bool mini_tap = MINI && do_x && tap - 3 == HALO_ROUNDS - 1;
+            if (do_x) { if (mini_tap) xm_begin(nb); else xf_begin(tap - 3, nb); }
 #pragma unroll
             for (int g = 0; g < NG; ++g) {
                 const int kk = g / (TM / 2), q0 = 2 * (g % (TM / 2));
@@ -441,7 +516,9 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / (TW / 16) / 2) void conv3x3
 #pragma unroll
                 for (int m = 0; m < 2 * TN; ++m) {
                     const int sidx = g * 2 * TN + m;
-                    mma_chunk<T>(acc[q0 + m / TN][m % TN], afs[g & 1][m / TN], bfs[kk][m % TN]);
+                    // weights are the first operand: accumulator register e of a lane is channel 8*(e/4) + 4*(lane>>5)
+                    // + e%4 of pixel lane&31, i.e. four consecutive channels per group of four registers
+                    mma_chunk<T>(acc[q0 + m / TN][m % TN], bfs[kk][m % TN], afs[g & 1][m / TN]);
                     if (sidx == 1) {
                         if (FUSE && tap == 0) dma_coef(ccn, nb);
                         if (tap < HALO_ROUNDS) dma_item(ccn, tap, nb);
@@ -453,7 +530,9 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / (TW / 16) / 2) void conv3x3
                     if (do_x) {
                         constexpr int NS = 2 * TM * TN;           // 16/NS transform pieces per MFMA
 #pragma unroll
-                        for (int xs = sidx * 16 / NS; xs < (sidx + 1) * 16 / NS; ++xs) xf_slot(xs, tap - 3);
+                        for (int xs = sidx * 16 / NS; xs < (sidx + 1) * 16 / NS; ++xs) {
+                            if (mini_tap) xm_slot(xs); else xf_slot(xs, tap - 3);
+                        }
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -519,14 +598,15 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / (TW / 16) / 2) void conv3x3
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
-                    for (int jn = 0; jn < TN; ++jn) mma_chunk<T>(acc[i][jn], af[i], bfr[jn]);
+                    for (int jn = 0; jn < TN; ++jn) mma_chunk<T>(acc[i][jn], bfr[jn], af[i]);
             }
         }
     }
     MAD_STAMP_PHASE(2)
 
     // ---- epilogue, 128 pixels (8 rows of one 16-column half) per pass.  Pixels in wave order: L = wm*TM*32 +
-    // tile*32 + row-in-tile = (half, row, column) = (L >> 8, (L >> 4) & 15, L & 15).
+    // tile*32 + row-in-tile = (half, row, column) = (L >> 8, (L >> 4) & 15, L & 15).  A lane hands over its
+    // pixel's channels four at a time, as 16-byte LDS writes.
     float* ctile = reinterpret_cast<float*>(smem);
     constexpr int WAVE_PIX = TM * 32;                        // pixels owned by one wave
     constexpr int NPASS = TW * 16 / 128;
@@ -545,9 +625,10 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / (TW / 16) / 2) void conv3x3
 #pragma unroll
                     for (int jn = 0; jn < TN; ++jn)
 #pragma unroll
-                        for (int e = 0; e < 16; ++e)
-                            ctile[(rbase + i * 32 + acc_row(e, lane)) * EPI_LD + wn * (TN * 32) + jn * 32 + (lane & 31)] =
-                                acc[i][jn][e];
+                        for (int g4 = 0; g4 < 4; ++g4) {
+                            const f32x4 v4 = {acc[i][jn][4 * g4], acc[i][jn][4 * g4 + 1], acc[i][jn][4 * g4 + 2], acc[i][jn][4 * g4 + 3]};
+                            *reinterpret_cast<f32x4*>(ctile + (rbase + i * 32 + fr) * EPI_LD + wn * (TN * 32) + jn * 32 + 8 * g4 + 4 * fh) = v4;
+                        }
             }
             __syncthreads();
             if (tid < 128) {
@@ -592,9 +673,10 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / (TW / 16) / 2) void conv3x3
 #pragma unroll
                 for (int jn = 0; jn < TN; ++jn)
 #pragma unroll
-                    for (int e = 0; e < 16; ++e)
-                        ctile[(rbase + i * 32 + acc_row(e, lane)) * EPI_LD + wn * (TN * 32) + jn * 32 + (lane & 31)] =
-                            acc[i][jn][e];
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        const f32x4 v4 = {acc[i][jn][4 * g4], acc[i][jn][4 * g4 + 1], acc[i][jn][4 * g4 + 2], acc[i][jn][4 * g4 + 3]};
+                        *reinterpret_cast<f32x4*>(ctile + (rbase + i * 32 + fr) * EPI_LD + wn * (TN * 32) + jn * 32 + 8 * g4 + 4 * fh) = v4;
+                    }
         }
         __syncthreads();
         MAD_STAMP_PHASE(4 + 3 * half)

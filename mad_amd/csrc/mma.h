@@ -36,16 +36,16 @@ __device__ __forceinline__ int acc_row(int j, int lane) { return (j & 3) + 8 * (
 // is the wave-uniform byte address `lds_wave_base` + lane*16; the global source is per lane.
 // Issued from inline asm so the compiler does not serialise it against the LDS reads of the
 // tile being multiplied: the caller waits with dma_wait_all() before the barrier that publishes
-// the tile.  M0 carries the LDS base and is saved/restored inside the statement.
+// the tile.  M0 carries the LDS base and is left holding it: M0 is a reserved register that the compiler never
+// allocates, and nothing it generates for these kernels reads M0 (LDS instructions take no M0 on gfx9 and later;
+// no indexed register moves, GWS or messages are used), so the two scalar moves per copy that saving and
+// restoring it cost are not spent.
 __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_wave_base) {
-    unsigned keep;
     asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %2\n\t"
+        "s_mov_b32 m0, %1\n\t"
         "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, off\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
+        "global_load_lds_dwordx4 %0, off"
+        :
         : "v"(gsrc), "s"(lds_wave_base)
         : "memory");
 }
@@ -53,14 +53,11 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_wave_base)
 // The same copy with a wave-uniform 64-bit base address (held in scalar registers) and a 32-bit byte offset
 // per lane: half the address registers and no 64-bit vector arithmetic per copy.
 __device__ __forceinline__ void glds16s(const void* sbase, unsigned voff, unsigned lds_wave_base) {
-    unsigned keep;
     asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %3\n\t"
+        "s_mov_b32 m0, %2\n\t"
         "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, %2\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
+        "global_load_lds_dwordx4 %0, %1"
+        :
         : "v"(voff), "s"(sbase), "s"(lds_wave_base)
         : "memory");
 }
