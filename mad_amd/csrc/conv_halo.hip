@@ -15,8 +15,9 @@
 //            during chunk c, one 16-byte item per thread per tap; each thread then rewrites its own
 //            item in place as y = silu(x*a+d) (zeros outside the image) three taps later.
 //   LDS    = halo pixels at 64-byte pitch, 18 pixels per row, chunk index XOR ((x>>1)&3);
-//            weight rows at 64-byte pitch, chunk index XOR ((row>>2)&3): both make every
-//            ds_read_b128 fragment read bank-conflict free for all nine tap shifts.
+//            weight rows at 64-byte pitch, chunk index XOR (-(row>>2)&3): both make every
+//            ds_read_b128 fragment read bank-conflict free for all nine tap shifts, with 32 rows x 2 chunks per
+//            wave (32x32x16 MFMA) and with 16 rows x 4 chunks (16x16x32 MFMA).
 //   Epilogue = per half tile: fp32 accumulators -> LDS -> coalesced 16-byte stores with bias and
 //            residual; per-channel sum / sum of squares of the stored values go to a
 //            (B, tiles, Cout, 2) slab in a fixed order (deterministic).
@@ -51,6 +52,24 @@ constexpr int HROW = 64;               // bytes per halo pixel / weight row per 
 template <int TW> constexpr int halo_items() { return HS * (TW + 2) * 4; }      // 16-byte items per halo chunk
 template <int TW> constexpr int halo_buf() { return (halo_items<TW>() + 63) / 64 * 64 * 16; }   // whole wave-instructions
 constexpr int CTAB_BYTES = 1024;       // one DMA instruction's worth; 256 (bf16) / 128 (fp32) bytes used
+// MFMA shape.  0: v_mfma_f32_32x32x16_bf16 everywhere; 1: v_mfma_f32_16x16x32_bf16 in the instantiations without the
+// loader transform; 2: everywhere.  (On this chip the 16x16x32 form sustains a higher clock for the same
+// multiplies; it issues twice as many matrix instructions, which the loader transform's vector work competes with.)
+#ifndef MAD_HALO_M16
+#define MAD_HALO_M16 1
+#endif
+// 1: the loader transform of a tap runs as one block in front of the tap's multiplies instead of in 16 pieces
+// between them (fewer registers live across the multiplies)
+#ifndef MAD_XF_PHASED
+#define MAD_XF_PHASED 0
+#endif
+// where in a tap (after which sixteenth of its MFMAs) the halo item and the weight tile of later taps are requested
+#ifndef MAD_DMA_HALO_SIDX
+#define MAD_DMA_HALO_SIDX 1
+#endif
+#ifndef MAD_DMA_W_SIDX
+#define MAD_DMA_W_SIDX 3
+#endif
 #ifndef MAD_HALO_PF
 #define MAD_HALO_PF 2
 #endif
@@ -122,6 +141,8 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / (TW / 16) / 2) void conv3x3
     constexpr int WMH = WM / (TW / 16);            // waves stacked along the rows of one 16-column half
     static_assert(WMH >= 2 && WM % (TW / 16) == 0, "a wave covers at most 8 rows of one half");
     constexpr int TM = 8 / WMH;                    // 32-pixel accumulator tiles per wave (2 tile rows each)
+    constexpr bool M16 = MAD_HALO_M16 >= 2 || (MAD_HALO_M16 == 1 && !FUSE);
+    constexpr int TM16 = 2 * TM, TN16 = 2 * TN;   // M16: 16-pixel (one tile row) and 16-channel fragments per wave
     constexpr int WTILE_BYTES = BN * HROW;
     constexpr int EPI_LD = BN + 4;
     constexpr int VEC = Elem<T>::VEC;
@@ -360,7 +381,7 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / (TW / 16) / 2) void conv3x3
     for (int j = 0; j < NW; ++j) {
         const int blk = (j * NWAVES + wave) % (BN / 16);   // 16-row block index
         const int r = blk * 16 + (lane >> 2);
-        const int lchunk = (lane & 3) ^ ((r >> 2) & 3);
+        const int lchunk = (lane & 3) ^ ((-(r >> 2)) & 3);
         wrow_off[j] = (unsigned)((r * 9 * Ctot + lchunk * VEC) * (int)sizeof(T));
     }
     auto stage_w = [&](int cc, int tap, int buf) {
@@ -373,31 +394,44 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / (TW / 16) / 2) void conv3x3
         }
     };
 
-    // ---- fragment addressing
-    const int fr = lane & 31, fh = lane >> 5;
-    int a_off[3][2];     // [kx][kk]: byte offset of this lane's A chunk for this wave's first tile row
+    // ---- fragment addressing.  32x32x16 form: lane&31 = row of a 32-row fragment, lane>>5 = which of two adjacent
+    // 16-byte chunks.  16x16x32 form (M16): lane&15 = row of a 16-row fragment (one tile row of pixels / 16
+    // channels), lane>>4 = chunk of the 64-byte row.
+    const int fr = M16 ? lane & 15 : lane & 31, fh = M16 ? lane >> 4 : lane >> 5;
+    int a_off[3][2];     // [kx][kk]: byte offset of this lane's pixel chunk for this wave's first tile row (M16: kk = 0)
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx) {
         const int hx = (wm / WMH) * 16 + (fr & 15) + kx;
-        const int pix = ((wm % WMH) * (16 / WMH) + (fr >> 4)) * HSX + hx;
+        const int pix = ((wm % WMH) * (16 / WMH) + (M16 ? 0 : fr >> 4)) * HSX + hx;
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) a_off[kx][kk] = pix * HROW + (((2 * kk + fh) ^ ((hx >> 1) & 3)) << 4);
+        for (int kk = 0; kk < 2; ++kk) a_off[kx][kk] = pix * HROW + ((((M16 ? 0 : 2 * kk) + fh) ^ ((hx >> 1) & 3)) << 4);
     }
-    int b_off[TN][2];    // [jn][kk]
+    // weight chunk of this lane: row r, and (32x32x16) the K half kk.  Rows 16 apart share their swizzle, so the
+    // fragments of a wave differ by a constant
+    int b_off[2];
+    {
+        const int r = wn * (TN * 32) + fr;
 #pragma unroll
-    for (int jn = 0; jn < TN; ++jn) {
-        const int r = wn * (TN * 32) + jn * 32 + fr;
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) b_off[jn][kk] = r * HROW + (((2 * kk + fh) ^ ((r >> 2) & 3)) << 4);
+        for (int kk = 0; kk < 2; ++kk) b_off[kk] = r * HROW + ((((M16 ? 0 : 2 * kk) + fh) ^ ((-(r >> 2)) & 3)) << 4);
     }
 
-    f32x16 acc[TM][TN];
+    f32x16 acc[M16 ? 1 : TM][M16 ? 1 : TN];
+    f32x4 acc16[M16 ? TM16 : 1][M16 ? TN16 : 1];
+    if constexpr (M16) {
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM16; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+            for (int j = 0; j < TN16; ++j)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+                for (int e = 0; e < 4; ++e) acc16[i][j][e] = 0.0f;
+    } else {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+    }
 
     // ---- prologue: the whole halo of chunk 0, its coefficients, weight tiles 0 and 1
     if (FUSE) dma_coef(0, 0);
@@ -489,52 +523,91 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / (TW / 16) / 2) void conv3x3
             // item tap-3 of the next chunk was issued three taps ago, before weight tile `tap`: it has landed,
             // and is transformed in place in 16 pieces behind this tap's 16 MFMAs
             const bool do_x = FUSE && tap >= 3 && tap - 3 < HALO_ROUNDS;
-            static_assert(TM % 2 == 0, "pixel tiles are multiplied in pairs");
-            constexpr int NG = TM;                     // groups of 2*TN MFMAs: (K half, pair of pixel tiles)
+            const bool mini_tap = MINI && do_x && tap - 3 == HALO_ROUNDS - 1;
+            // what rides behind MFMA number sidx of the tap's NMM: the requests for later taps and (unless the
+            // transform runs as one block) the transform pieces
+            auto behind_mma = [&](int sidx, int NMM) {
+                if (sidx == MAD_DMA_HALO_SIDX * NMM / 16) {
+                    if (FUSE && tap == 0) dma_coef(ccn, nb);
+                    if (tap < HALO_ROUNDS) dma_item(ccn, tap, nb);
+                }
+                if (sidx == MAD_DMA_W_SIDX * NMM / 16) {
+                    if (tap + PF < 9) stage_w(cc, tap + PF, wbuf(cc, tap + PF));
+                    else stage_w(ccn, tap + PF - 9, wbuf(cc + 1, tap + PF - 9));
+                }
+                if (do_x && !MAD_XF_PHASED) {
+#pragma unroll
+                    for (int xs = sidx * 16 / NMM; xs < (sidx + 1) * 16 / NMM; ++xs) {
+                        if (mini_tap) xm_slot(xs); else xf_slot(xs, tap - 3);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            if (do_x && MAD_XF_PHASED) {
+                if (mini_tap) xm_begin(nb); else xf_begin(tap - 3, nb);
+#pragma unroll
+                for (int xs = 0; xs < 16; ++xs) {
+                    if (mini_tap) xm_slot(xs); else xf_slot(xs, tap - 3);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
             // bf16: the fragments of a group are requested while the group before it is multiplied (measured
             // a little faster than requesting all of a tap's fragments at its top); the fp32 parity form has no
             // registers to spare and requests each group when it needs it
             constexpr bool AHEAD = sizeof(T) == 2;
-            uint4 afs[2][2], bfs[2][TN];
-            auto read_group = [&](int g) {
-                const int kk = g / (TM / 2), q0 = 2 * (g % (TM / 2));
-                if (q0 == 0) {
+            if constexpr (M16) {
+                constexpr int NG = TM16 / 2;           // groups of 2*TN16 MFMAs: a pair of pixel rows x all channels
+                constexpr int NMM = TM16 * TN16;
+                uint4 afs[2][2], bfs[TN16];
+                auto read_group = [&](int g) {
+                    if (g == 0) {
 #pragma unroll
-                    for (int q = 0; q < TN; ++q) bfs[kk][q] = *reinterpret_cast<const uint4*>(wt + b_off[q][kk]);
+                        for (int q = 0; q < TN16; ++q) bfs[q] = *reinterpret_cast<const uint4*>(wt + b_off[0] + q * 16 * HROW);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+                        afs[g & 1][q] = *reinterpret_cast<const uint4*>(halo + a_off[kx][0] + (2 * g + q + ky) * HSX * HROW);
+                };
+                read_group(0);
+                if (do_x && !MAD_XF_PHASED) { if (mini_tap) xm_begin(nb); else xf_begin(tap - 3, nb); }
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    if (AHEAD ? g + 1 < NG : g > 0) read_group(AHEAD ? g + 1 : g);
+#pragma unroll
+                    for (int m = 0; m < 2 * TN16; ++m) {
+                        // weights are the first operand: a lane's four results are four consecutive channels of a pixel
+                        mma16_row<T>(acc16[2 * g + m / TN16][m % TN16], bfs[m % TN16], afs[g & 1][m / TN16]);
+                        behind_mma(g * 2 * TN16 + m, NMM);
+                    }
                 }
+            } else {
+                static_assert(TM % 2 == 0, "pixel tiles are multiplied in pairs");
+                constexpr int NG = TM;                     // groups of 2*TN MFMAs: (K half, pair of pixel tiles)
+                constexpr int NMM = 2 * TM * TN;
+                uint4 afs[2][2], bfs[2][TN];
+                auto read_group = [&](int g) {
+                    const int kk = g / (TM / 2), q0 = 2 * (g % (TM / 2));
+                    if (q0 == 0) {
 #pragma unroll
-                for (int q = 0; q < 2; ++q)
-                    afs[g & 1][q] = *reinterpret_cast<const uint4*>(halo + a_off[kx][kk] + (2 * (q0 + q) + ky) * HSX * HROW);
-            };
-            read_group(0);
-            const bool mini_tap = MINI && do_x && tap - 3 == HALO_ROUNDS - 1;
-            if (do_x) { if (mini_tap) xm_begin(nb); else xf_begin(tap - 3, nb); }
-#pragma unroll
-            for (int g = 0; g < NG; ++g) {
-                const int kk = g / (TM / 2), q0 = 2 * (g % (TM / 2));
-                if (AHEAD ? g + 1 < NG : g > 0) read_group(AHEAD ? g + 1 : g);
-#pragma unroll
-                for (int m = 0; m < 2 * TN; ++m) {
-                    const int sidx = g * 2 * TN + m;
-                    // weights are the first operand: accumulator register e of a lane is channel 8*(e/4) + 4*(lane>>5)
-                    // + e%4 of pixel lane&31, i.e. four consecutive channels per group of four registers
-                    mma_chunk<T>(acc[q0 + m / TN][m % TN], bfs[kk][m % TN], afs[g & 1][m / TN]);
-                    if (sidx == 1) {
-                        if (FUSE && tap == 0) dma_coef(ccn, nb);
-                        if (tap < HALO_ROUNDS) dma_item(ccn, tap, nb);
+                        for (int q = 0; q < TN; ++q) bfs[kk][q] = *reinterpret_cast<const uint4*>(wt + b_off[kk] + q * 32 * HROW);
                     }
-                    if (sidx == 3 || (2 * TM * TN < 4 && sidx == 2 * TM * TN - 1)) {
-                        if (tap + PF < 9) stage_w(cc, tap + PF, wbuf(cc, tap + PF));
-                        else stage_w(ccn, tap + PF - 9, wbuf(cc + 1, tap + PF - 9));
-                    }
-                    if (do_x) {
-                        constexpr int NS = 2 * TM * TN;           // 16/NS transform pieces per MFMA
 #pragma unroll
-                        for (int xs = sidx * 16 / NS; xs < (sidx + 1) * 16 / NS; ++xs) {
-                            if (mini_tap) xm_slot(xs); else xf_slot(xs, tap - 3);
-                        }
+                    for (int q = 0; q < 2; ++q)
+                        afs[g & 1][q] = *reinterpret_cast<const uint4*>(halo + a_off[kx][kk] + (2 * (q0 + q) + ky) * HSX * HROW);
+                };
+                read_group(0);
+                if (do_x && !MAD_XF_PHASED) { if (mini_tap) xm_begin(nb); else xf_begin(tap - 3, nb); }
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    const int kk = g / (TM / 2), q0 = 2 * (g % (TM / 2));
+                    if (AHEAD ? g + 1 < NG : g > 0) read_group(AHEAD ? g + 1 : g);
+#pragma unroll
+                    for (int m = 0; m < 2 * TN; ++m) {
+                        // weights are the first operand: accumulator register e of a lane is channel 8*(e/4) +
+                        // 4*(lane>>5) + e%4 of pixel lane&31, i.e. four consecutive channels per four registers
+                        mma_chunk<T>(acc[q0 + m / TN][m % TN], bfs[kk][m % TN], afs[g & 1][m / TN]);
+                        behind_mma(g * 2 * TN + m, NMM);
                     }
-                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
             MAD_STAMP(3)
@@ -560,7 +633,7 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / (TW / 16) / 2) void conv3x3
             for (int j = 0; j < SK_ROUNDS; ++j) {
                 const int item = tid + NT * j;
                 const int pp = item >> 2;
-                const int lc = (tid & 3) ^ ((pp >> 2) & 3);
+                const int lc = (tid & 3) ^ ((-(pp >> 2)) & 3);
                 const size_t pix = ((size_t)b * a.H + ty0 + ((pp >> 4) & 15)) * a.W + tx0 + (pp >> 8) * 16 + (pp & 15);
                 glds16(src + pix * cs + coff + lc * VEC,
                        __builtin_amdgcn_readfirstlane(halo_base + buf * HALO_BUF + (NT * j + 64 * wave) * 16));
@@ -569,7 +642,7 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / (TW / 16) / 2) void conv3x3
             for (int j = 0; j < NW; ++j) {
                 const int blk = (j * NWAVES + wave) % (BN / 16);
                 const int r = blk * 16 + (lane >> 2);
-                const int lchunk = (lane & 3) ^ ((r >> 2) & 3);
+                const int lchunk = (lane & 3) ^ ((-(r >> 2)) & 3);
                 const T* g = (const T*)a.sw + (size_t)(n0 + r) * Cs + c0 + lchunk * VEC;
                 glds16(g, __builtin_amdgcn_readfirstlane(wt_base + buf * WTILE_BYTES + blk * 16 * HROW));
             }
@@ -578,7 +651,7 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / (TW / 16) / 2) void conv3x3
         {
             const int r = wm * (TM * 32) + fr;
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) s_off[kk] = r * HROW + (((2 * kk + fh) ^ ((r >> 2) & 3)) << 4);
+            for (int kk = 0; kk < 2; ++kk) s_off[kk] = r * HROW + ((((M16 ? 0 : 2 * kk) + fh) ^ ((-(r >> 2)) & 3)) << 4);
         }
         __syncthreads();                     // every wave has finished reading the last 3x3 tiles
         dma_skip(0, 0);
@@ -588,17 +661,29 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / (TW / 16) / 2) void conv3x3
             if (sc + 1 < nskip) dma_skip(sc + 1, (sc + 1) & 1);
             const unsigned char* sa = halo0 + (sc & 1) * HALO_BUF;
             const unsigned char* wt = wt0 + (sc & 1) * WTILE_BYTES;
+            if constexpr (M16) {
+                uint4 af[TM16], bfr[TN16];
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                uint4 af[TM], bfr[TN];
+                for (int i = 0; i < TM16; ++i) af[i] = *reinterpret_cast<const uint4*>(sa + s_off[0] + i * 16 * HROW);
 #pragma unroll
-                for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const uint4*>(sa + s_off[kk] + i * 32 * HROW);
+                for (int jn = 0; jn < TN16; ++jn) bfr[jn] = *reinterpret_cast<const uint4*>(wt + b_off[0] + jn * 16 * HROW);
 #pragma unroll
-                for (int jn = 0; jn < TN; ++jn) bfr[jn] = *reinterpret_cast<const uint4*>(wt + b_off[jn][kk]);
+                for (int i = 0; i < TM16; ++i)
 #pragma unroll
-                for (int i = 0; i < TM; ++i)
+                    for (int jn = 0; jn < TN16; ++jn) mma16_row<T>(acc16[i][jn], bfr[jn], af[i]);
+            } else {
 #pragma unroll
-                    for (int jn = 0; jn < TN; ++jn) mma_chunk<T>(acc[i][jn], bfr[jn], af[i]);
+                for (int kk = 0; kk < 2; ++kk) {
+                    uint4 af[TM], bfr[TN];
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const uint4*>(sa + s_off[kk] + i * 32 * HROW);
+#pragma unroll
+                    for (int jn = 0; jn < TN; ++jn) bfr[jn] = *reinterpret_cast<const uint4*>(wt + b_off[kk] + jn * 32 * HROW);
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int jn = 0; jn < TN; ++jn) mma_chunk<T>(acc[i][jn], bfr[jn], af[i]);
+                }
             }
         }
     }
@@ -611,6 +696,26 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / (TW / 16) / 2) void conv3x3
     constexpr int WAVE_PIX = TM * 32;                        // pixels owned by one wave
     constexpr int NPASS = TW * 16 / 128;
     static_assert(WAVE_PIX <= 128 && 128 % WAVE_PIX == 0, "a wave's pixels lie inside one pass");
+    // this wave's accumulators -> ctile rows rbase.. (fp32, EPI_LD floats per pixel), four consecutive channels per write
+    auto hand_over = [&](int rbase) {
+        if constexpr (M16) {
+#pragma unroll
+            for (int i = 0; i < TM16; ++i)
+#pragma unroll
+                for (int jn = 0; jn < TN16; ++jn)
+                    *reinterpret_cast<f32x4*>(ctile + (rbase + i * 16 + fr) * EPI_LD + wn * (TN * 32) + jn * 16 + 4 * fh) = acc16[i][jn];
+        } else {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int jn = 0; jn < TN; ++jn)
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        const f32x4 v4 = {acc[i][jn][4 * g4], acc[i][jn][4 * g4 + 1], acc[i][jn][4 * g4 + 2], acc[i][jn][4 * g4 + 3]};
+                        *reinterpret_cast<f32x4*>(ctile + (rbase + i * 32 + fr) * EPI_LD + wn * (TN * 32) + jn * 32 + 8 * g4 + 4 * fh) = v4;
+                    }
+        }
+    };
     auto pix_y = [&](int L) { return ty0 + ((L >> 4) & 15); };
     auto pix_x = [&](int L) { return tx0 + (L >> 8) * 16 + (L & 15); };
     if constexpr (OUT_NCHW) {
@@ -620,15 +725,7 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / (TW / 16) / 2) void conv3x3
             __syncthreads();
             if ((wm * WAVE_PIX) / 128 == half) {
                 const int rbase = wm * WAVE_PIX - half * 128;
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int jn = 0; jn < TN; ++jn)
-#pragma unroll
-                        for (int g4 = 0; g4 < 4; ++g4) {
-                            const f32x4 v4 = {acc[i][jn][4 * g4], acc[i][jn][4 * g4 + 1], acc[i][jn][4 * g4 + 2], acc[i][jn][4 * g4 + 3]};
-                            *reinterpret_cast<f32x4*>(ctile + (rbase + i * 32 + fr) * EPI_LD + wn * (TN * 32) + jn * 32 + 8 * g4 + 4 * fh) = v4;
-                        }
+                hand_over(rbase);
             }
             __syncthreads();
             if (tid < 128) {
@@ -668,15 +765,7 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / (TW / 16) / 2) void conv3x3
         MAD_STAMP_PHASE(3 + 3 * half)
         if ((wm * WAVE_PIX) / 128 == half) {
             const int rbase = wm * WAVE_PIX - half * 128;
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int jn = 0; jn < TN; ++jn)
-#pragma unroll
-                    for (int g4 = 0; g4 < 4; ++g4) {
-                        const f32x4 v4 = {acc[i][jn][4 * g4], acc[i][jn][4 * g4 + 1], acc[i][jn][4 * g4 + 2], acc[i][jn][4 * g4 + 3]};
-                        *reinterpret_cast<f32x4*>(ctile + (rbase + i * 32 + fr) * EPI_LD + wn * (TN * 32) + jn * 32 + 8 * g4 + 4 * fh) = v4;
-                    }
+            hand_over(rbase);
         }
         __syncthreads();
         MAD_STAMP_PHASE(4 + 3 * half)

@@ -29,6 +29,25 @@ template <> __device__ __forceinline__ void mma_chunk<float>(f32x16& acc, const 
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
 }
 
+// The 16x16 forms: every lane reads ONE 16-byte chunk of a 64-byte row, lane&15 selects the row and lane>>4
+// which of its four chunks.  bf16: v_mfma_f32_16x16x32_bf16 consumes the whole 64-byte row (k = 8*(lane>>4)..+7 per
+// lane); fp32: four v_mfma_f32_16x16x4_f32, element e of each lane per instruction (k order permuted identically
+// for both operands).  Accumulator register j of a lane is row 4*(lane>>4) + j of the FIRST operand, column
+// lane&15 of the second.
+template <typename T> __device__ __forceinline__ void mma16_row(f32x4& acc, const uint4& a, const uint4& b);
+
+template <> __device__ __forceinline__ void mma16_row<bf16_t>(f32x4& acc, const uint4& a, const uint4& b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc,
+                                                   0, 0, 0);
+}
+
+template <> __device__ __forceinline__ void mma16_row<float>(f32x4& acc, const uint4& a, const uint4& b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(b.z), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
+}
+
 // Row of the 32x32 accumulator held in register j of this lane (column = lane & 31).
 __device__ __forceinline__ int acc_row(int j, int lane) { return (j & 3) + 8 * (j >> 2) + 4 * (lane >> 5); }
 
