@@ -23,6 +23,7 @@
 //            (B, tiles, Cout, 2) slab in a fixed order (deterministic).
 #include "mma.h"
 #include <cstdlib>
+#include <type_traits>
 
 namespace mad {
 
@@ -486,10 +487,13 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / (TW / 16) / 2) void conv3x3
     //   N(t) = sum over x = t-PF+1 .. t-1 of coef(x) + item(x) + NW          (indices mod 9)
     // and a halo item issued at tap j has landed when the wait of tap j+PF is over.
     MAD_STAMP_PHASE(1)
-    for (int cc = 0; cc < nchunks; ++cc) {
+    // The body of one channel chunk.  The last chunk of a tile has nothing to fetch or transform for a next chunk:
+    // its instantiation (LAST) requests only the weight tiles it still needs, and its waits count accordingly.
+    auto chunk_body = [&](const int cc, auto last_tag) {
+        constexpr bool LAST = decltype(last_tag)::value;
         const unsigned char* halo = halo0 + (cc & 1) * HALO_BUF;
         const int nb = (cc + 1) & 1;                              // halo / table buffer of the next chunk
-        const int ccn = cc + 1 < nchunks ? cc + 1 : cc;           // last chunk: harmless restaging of itself
+        const int ccn = cc + 1;
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int ky = tap / 3, kx = tap % 3;
@@ -499,12 +503,15 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / (TW / 16) / 2) void conv3x3
 #pragma unroll
             for (int d = 1; d < PF; ++d) {
                 const int x = (tap + 9 - d) % 9;
-                nwait += (x == 0 ? C0 : 0) + (x < HALO_ROUNDS ? 1 : 0) + NW;
+                // tap x of this chunk when x < tap, else of the chunk before (never a LAST one)
+                if (LAST && x < tap) nwait += x + PF < 9 ? NW : 0;
+                else nwait += (x == 0 ? C0 : 0) + (x < HALO_ROUNDS ? 1 : 0) + NW;
             }
             // weight tile `tap` has landed; after the barrier it and (at tap 0) the finished halo of this
             // chunk are visible to every wave, and every wave is done with the buffers refilled below
             MAD_STAMP(0)
             switch (nwait) {
+                case 0: dma_wait_upto<0>(); break;
                 case 1: dma_wait_upto<1>(); break;
                 case 2: dma_wait_upto<2>(); break;
                 case 3: dma_wait_upto<3>(); break;
@@ -522,18 +529,18 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / (TW / 16) / 2) void conv3x3
             const unsigned char* wt = wt0 + wbuf(cc, tap) * WTILE_BYTES;
             // item tap-3 of the next chunk was issued three taps ago, before weight tile `tap`: it has landed,
             // and is transformed in place in 16 pieces behind this tap's 16 MFMAs
-            const bool do_x = FUSE && tap >= 3 && tap - 3 < HALO_ROUNDS;
+            const bool do_x = FUSE && !LAST && tap >= 3 && tap - 3 < HALO_ROUNDS;
             const bool mini_tap = MINI && do_x && tap - 3 == HALO_ROUNDS - 1;
             // what rides behind MFMA number sidx of the tap's NMM: the requests for later taps and (unless the
             // transform runs as one block) the transform pieces
             auto behind_mma = [&](int sidx, int NMM) {
-                if (sidx == MAD_DMA_HALO_SIDX * NMM / 16) {
+                if (!LAST && sidx == MAD_DMA_HALO_SIDX * NMM / 16) {
                     if (FUSE && tap == 0) dma_coef(ccn, nb);
                     if (tap < HALO_ROUNDS) dma_item(ccn, tap, nb);
                 }
                 if (sidx == MAD_DMA_W_SIDX * NMM / 16) {
                     if (tap + PF < 9) stage_w(cc, tap + PF, wbuf(cc, tap + PF));
-                    else stage_w(ccn, tap + PF - 9, wbuf(cc + 1, tap + PF - 9));
+                    else if (!LAST) stage_w(ccn, tap + PF - 9, wbuf(cc + 1, tap + PF - 9));
                 }
                 if (do_x && !MAD_XF_PHASED) {
 #pragma unroll
@@ -613,8 +620,10 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / (TW / 16) / 2) void conv3x3
             MAD_STAMP(3)
             MAD_STAMP(4)
         }
-    }
-    dma_wait_all();      // the restaging copies of the last chunk must land before LDS is reused below
+    };
+    for (int cc = 0; cc < nchunks - 1; ++cc) chunk_body(cc, std::false_type{});
+    chunk_body(nchunks - 1, std::true_type{});
+    dma_wait_all();
 
     // ---- 1x1 projection of the block input (the residual branch's channel change), accumulated into the
     // same tiles: K is extended by SC1+SC2 channels read at the centre tap from the raw, un-normalised
