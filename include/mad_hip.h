@@ -122,9 +122,11 @@ int mad_conv_in_stats(const float* x, const float* w, const float* bias, void* y
 int mad_conv_out(const void* x, int dtype, const float* w, const float* bias, float* y, int B,
                  int Cin, int H, int W, int Cout, void* stream);
 
-/* Last convolution on the halo-tile MFMA kernel, with out_norm + SiLU folded into the loader:
+/* Last convolution with out_norm + SiLU folded into the loader:
  * y (B,Cout<=32,H,W) NCHW fp32 = conv3x3(act(x*coef[...,0] + coef[...,1])) + bias.  x NHWC (B,H,W,Cin),
- * w (32,3,3,Cin) in `dtype` with rows >= Cout zero, H and W multiples of 16.
+ * w (32,3,3,Cin) in `dtype` with rows >= Cout zero, H and W multiples of 16.  bf16 with Cout <= 3 and
+ * Cin <= 256 runs the tap-major kernel (the nine taps as the N dimension of one product per halo pixel,
+ * every input pixel read and transformed once per tile); other cases run the halo-tile MFMA kernel.
  * Replaces out_conv(silu(out_norm(x))) (model.py:589). */
 int mad_conv_out_fused(const void* x, int Cin, const float* coef, int act, const void* w,
                        const float* bias, float* y, int dtype, int B, int H, int W, int Cout,

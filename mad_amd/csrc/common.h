@@ -12,6 +12,11 @@ namespace mad {
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);
 
+// tap-major form of the last layer (conv_out.hip): bf16 activations, at most 3 output channels
+bool conv_out_taps_ok(int Cin, int H, int W, int Cout);
+int conv_out_taps(const void* x, int Cin, const float* coef, int act, const void* w, const float* bias, float* y, int B,
+                  int H, int W, int Cout, hipStream_t s);
+
 #define MAD_REQUIRE(cond, ...)              \
     do {                                    \
         if (!(cond)) {                      \

@@ -1072,6 +1072,9 @@ extern "C" int mad_conv_out_fused(const void* x, int Cin, const float* coef, int
     MAD_REQUIRE(B > 0 && H >= 16 && W >= 16 && H % 16 == 0 && W % 16 == 0,
                 "mad_conv_out_fused: H=%d, W=%d must be multiples of 16", H, W);
     MAD_REQUIRE((size_t)B * H * W < (1u << 31), "mad_conv_out_fused: tensor too large for 32-bit pixel indices");
+    // up to three output channels: the nine taps are the N dimension of one product per halo pixel (conv_out.hip)
+    if (dtype == MAD_BF16 && conv_out_taps_ok(Cin, H, W, Cout) && !getenv("MAD_CONV_OUT_HALO"))
+        return conv_out_taps(x, Cin, coef, act, w, bias, y, B, H, W, Cout, (hipStream_t)stream);
     HaloArgs a;
     a.x1 = x; a.x2 = x; a.w = w; a.bias = bias; a.coef = coef; a.residual = nullptr; a.y = y; a.stats = nullptr;
     a.C1 = Cin; a.C2 = 0; a.B = B; a.H = H; a.W = W; a.Cout = Cout; a.upsample = 0; a.res_mode = MAD_RES_NONE;
