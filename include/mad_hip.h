@@ -174,7 +174,10 @@ int mad_conv2d_ws(const void* x1, int C1, const void* x2, int C2, const void* w,
  *   in(b,y,x,c) = act(x(b,y,x,c)*coef[b,c,0] + coef[b,c,1])   (coef NULL: in = x; zero outside the image)
  *   y = conv3x3(in) + bias (+ residual as in mad_conv2d)
  *   stats[b, tile, n, 0/1] = sum / sum of squares of y over the 16x16 tile (tile = ty*(W/16)+tx);
- *   stats may be NULL.  mad_gn_finalize consumes it with nsplit = (H/16)*(W/16).
+ *   stats may be NULL.  mad_gn_finalize consumes it with nsplit = (H/16)*(W/16).  In bf16 the sums are
+ *   taken per channel PAIR: slot n = 2i holds the sums over channels 2i and 2i+1, slot 2i+1 holds zeros
+ *   (the GroupNorm that consumes them must have an even number of channels per group, as every
+ *   GroupNorm of the reference has: model.py:174-181).
  * x is the concatenation of x1 (C1) and x2 (C2), NHWC at (H,W), or at (H/2,W/2) when `upsample`.
  * C1, C2 multiples of 32 (bf16) / 16 (fp32).  act: 0 none, 1 SiLU.
  * Replaces GroupNorm -> SiLU -> Conv2d (model.py:341, 346-350) and the statistics pass of the

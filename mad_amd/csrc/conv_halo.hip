@@ -19,8 +19,9 @@
 //            ds_read_b128 fragment read bank-conflict free for all nine tap shifts, with 32 rows x 2 chunks per
 //            wave (32x32x16 MFMA) and with 16 rows x 4 chunks (16x16x32 MFMA).
 //   Epilogue = per half tile: fp32 accumulators -> LDS -> coalesced 16-byte stores with bias and
-//            residual; per-channel sum / sum of squares of the stored values go to a
-//            (B, tiles, Cout, 2) slab in a fixed order (deterministic).
+//            residual; sum / sum of squares of the stored values go to a (B, tiles, Cout, 2) slab in a
+//            fixed order (deterministic).  fp32: per channel.  bf16: per channel PAIR (2i, 2i+1), both sums in
+//            slot 2i and zeros in slot 2i+1 -- a GroupNorm group holds whole pairs and only group sums are used.
 #include "mma.h"
 #include <cstdlib>
 #include <type_traits>
@@ -70,6 +71,10 @@ constexpr int CTAB_BYTES = 1024;       // one DMA instruction's worth; 256 (bf16
 #endif
 #ifndef MAD_DMA_W_SIDX
 #define MAD_DMA_W_SIDX 3
+#endif
+// 1: the bf16 epilogue takes the output statistics over channel pairs with v_dot2c_f32_bf16 (see the epilogue)
+#ifndef MAD_STATS_DOT2
+#define MAD_STATS_DOT2 1
 #endif
 #ifndef MAD_HALO_PF
 #define MAD_HALO_PF 2
@@ -818,9 +823,23 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / (TW / 16) / 2) void conv3x3
             if constexpr (GSTAT) {
                 // sums taken after both halves are stored (below): the accumulators are dead by then
             } else if (a.stats) {
+#if MAD_STATS_DOT2
+                if constexpr (sizeof(T) == 2) {
+                    // sums over channel PAIRS, straight from the packed bf16 pairs (one instruction per pair and
+                    // quantity): a GroupNorm group holds whole pairs, and only group sums are ever used
+                    const unsigned* w4 = reinterpret_cast<const unsigned*>(&o.raw);
+#pragma unroll
+                    for (int k = 0; k < VEC / 2; ++k) {
+                        asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(ssum[2 * k]) : "v"(w4[k]), "v"(0x3f803f80u));
+                        asm("v_dot2c_f32_bf16 %0, %1, %1" : "+v"(ssq[2 * k]) : "v"(w4[k]));
+                    }
+                } else
+#endif
+                {
                 float f[VEC]; o.unpack(f);          // statistics of the values as stored
 #pragma unroll
                 for (int i = 0; i < VEC; ++i) { ssum[i] += f[i]; ssq[i] = fmaf(f[i], f[i], ssq[i]); }
+                }
             }
         }
         MAD_STAMP_PHASE(5 + 3 * half)
