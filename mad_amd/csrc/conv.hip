@@ -28,6 +28,9 @@ struct ConvArgs {
     // split-K form: blockIdx.y takes one of `ksplit` contiguous shares of the K-tiles and writes its fp32 partial
     // tile to partial[share][M][Cout]; conv_splitk_finish_kernel adds the shares in order and does the epilogue
     float* partial; int ksplit;
+    // 1x1, no resampling, 32-bit byte offsets suffice: the activation copies are addressed as a scalar base plus
+    // a per-lane offset that never changes (no vector address arithmetic per K-tile)
+    int fast1;
 };
 
 constexpr int ROWB = 128;   // bytes per LDS row = one K-tile of one operand row
@@ -52,7 +55,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
     static_assert((NST - 2) * PPW < 64, "outstanding copies must fit the vmcnt field");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
 
     // XCD-aware tile order: blocks id, id+8, ... share an XCD (and its L2); give each XCD a
@@ -88,6 +91,19 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
         }
     }
 
+    // Addressing without per-copy vector arithmetic.  Row r = (j*4+wave)*8 + lrow of a tile sits 32*j rows below
+    // row wave*8 + lrow, and (r >> 1) & 7 does not depend on j: a copy is a scalar base (tile, tap, channel chunk,
+    // j) plus ONE per-lane byte offset.  Always so for the weight rows; for the activation rows when the layer is
+    // 1x1 without resampling (pixel m reads pixel m) and the tile is a whole one.
+    const int lchunk_f = pchunk ^ (((wave & 1) * 4 + (lrow >> 1)) & 7);
+    const unsigned woff = (unsigned)(((wave * 8 + lrow) * ntaps * Ctot + lchunk_f * VEC) * (int)sizeof(T));
+    const bool fastA = a.fast1 && m0 + BM <= a.M;
+    const unsigned aoff1 = (unsigned)(((m0 + wave * 8 + lrow) * a.C1 + lchunk_f * VEC) * (int)sizeof(T));
+    const unsigned aoff2 = (unsigned)(((m0 + wave * 8 + lrow) * a.C2 + lchunk_f * VEC) * (int)sizeof(T));
+
+    const T* apj[APW];       // general form: this lane's source rows for the (tap, source) pair a_key
+    int a_key = -1;
+
     const unsigned smem_base = lds_addr(smem);
     auto stage = [&](int kt, int buf) {
         const int tap = kt / cchunks, cc = kt - tap * cchunks;
@@ -98,27 +114,35 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
         else { src = (const T*)a.x2; cs = a.C2; coff = c0 - a.C1; }
         const unsigned abuf = smem_base + buf * (A_BYTES + B_BYTES);
         const unsigned bbuf = abuf + A_BYTES;
+        if (fastA) {
+            const unsigned ao = c0 < a.C1 ? aoff1 : aoff2;
 #pragma unroll
-        for (int j = 0; j < APW; ++j) {
-            const int r = (j * 4 + wave) * 8 + lrow;
-            const int lchunk = pchunk ^ ((r >> 1) & 7);
-            const int iy = a_oy[j] + ky - pad, ix = a_ox[j] + kx - pad;
-            const bool ok = a_b[j] >= 0 && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-            // clamp so the address is always in range, then select the zero page for padding
-            const int cy = min(max(iy, 0), a.H - 1), cx = min(max(ix, 0), a.W - 1);
-            const int sy = a.upsample ? cy >> 1 : cy, sx = a.upsample ? cx >> 1 : cx;
-            const int bb = max(a_b[j], 0);
-            const T* p = src + ((size_t)((bb * a.Hs + sy) * a.Ws + sx)) * cs + coff + lchunk * VEC;
-            const void* g = ok ? (const void*)p : (const void*)g_zero_page;
-            glds16(g, __builtin_amdgcn_readfirstlane(abuf + (j * 4 + wave) * 8 * ROWB));
-        }
+            for (int j = 0; j < APW; ++j)
+                glds16s(src + coff + (size_t)(j * 32) * cs, ao, abuf + (j * 4 + wave) * 8 * ROWB);
+        } else {
+            // the row pointers of a (tap, source) pair are worked out once and serve all its channel chunks
+            const int key = tap * 2 + (c0 < a.C1 ? 0 : 1);
+            if (key != a_key) {
+                a_key = key;
 #pragma unroll
-        for (int j = 0; j < BPW; ++j) {
-            const int r = (j * 4 + wave) * 8 + lrow;
-            const int lchunk = pchunk ^ ((r >> 1) & 7);
-            const T* g = (const T*)a.w + ((size_t)(n0 + r) * ntaps + tap) * Ctot + c0 + lchunk * VEC;
-            glds16(g, __builtin_amdgcn_readfirstlane(bbuf + (j * 4 + wave) * 8 * ROWB));
+                for (int j = 0; j < APW; ++j) {
+                    const int iy = a_oy[j] + ky - pad, ix = a_ox[j] + kx - pad;
+                    const bool ok = a_b[j] >= 0 && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+                    // clamp so the address is always in range, then select the zero page for padding
+                    const int cy = min(max(iy, 0), a.H - 1), cx = min(max(ix, 0), a.W - 1);
+                    const int sy = a.upsample ? cy >> 1 : cy, sx = a.upsample ? cx >> 1 : cx;
+                    const int bb = max(a_b[j], 0);
+                    const T* p = src + ((size_t)((bb * a.Hs + sy) * a.Ws + sx)) * cs + lchunk_f * VEC;
+                    apj[j] = ok ? p : reinterpret_cast<const T*>(g_zero_page) + lchunk_f * VEC;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < APW; ++j) glds16(apj[j] + coff, abuf + (j * 4 + wave) * 8 * ROWB);
         }
+        const T* wb = (const T*)a.w + ((size_t)n0 * ntaps + tap) * Ctot + c0;
+#pragma unroll
+        for (int j = 0; j < BPW; ++j)
+            glds16s(wb + (size_t)(j * 32) * ntaps * Ctot, woff, bbuf + (j * 4 + wave) * 8 * ROWB);
     };
 
     f32x16 acc[TM][TN];
@@ -734,6 +758,8 @@ static int conv2d_impl(const void* x1, int C1, const void* x2, int C2, const voi
     MAD_REQUIRE(C1 > 0 && C1 % 64 == 0 && C2 >= 0 && C2 % 64 == 0 && (C2 == 0 || x2),
                 "mad_conv2d: C1=%d, C2=%d must be multiples of 64 (x2 given when C2 > 0)", C1, C2);
     MAD_REQUIRE(Cout > 0 && Cout % 64 == 0, "mad_conv2d: Cout=%d must be a multiple of 64", Cout);
+    MAD_REQUIRE((size_t)(C1 > C2 ? C1 : C2) * (dtype == MAD_BF16 ? 2 : 4) <= (size_t)MAD_ZERO_PAGE_BYTES,
+                "mad_conv2d: %d channels per source exceed the zero page", C1 > C2 ? C1 : C2);
     MAD_REQUIRE(B > 0 && H > 0 && W > 0 && (size_t)B * H * W < (1u << 31), "mad_conv2d: bad shape B=%d H=%d W=%d", B, H, W);
     MAD_REQUIRE(!upsample || (H % 2 == 0 && W % 2 == 0), "mad_conv2d: upsample needs even H, W");
     MAD_REQUIRE(res_mode >= MAD_RES_NONE && res_mode <= MAD_RES_DOWN && (res_mode == MAD_RES_NONE || residual),
@@ -744,6 +770,8 @@ static int conv2d_impl(const void* x1, int C1, const void* x2, int C2, const voi
     a.C1 = C1; a.C2 = C2; a.B = B; a.H = H; a.W = W; a.Cout = Cout; a.ksize = ksize; a.upsample = upsample;
     a.res_mode = res_mode; a.M = B * H * W; a.stats = stats;
     a.partial = nullptr; a.ksplit = 1;
+    a.fast1 = ksize == 1 && !upsample &&
+              (size_t)B * H * W * (C1 > C2 ? C1 : C2) * (dtype == MAD_BF16 ? 2 : 4) < ((size_t)1 << 32);
     if (workspace) {
         const int ks = plan_ksplit(a.M, Cout, C1 + C2, ksize, dtype);
         if (ks > 1) {

@@ -90,8 +90,10 @@ template <int N> __device__ __forceinline__ void dma_wait_upto() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-// Source of LDS-DMA copies that must deliver zeros (conv padding, rows past the end).
-__device__ __attribute__((aligned(256))) const unsigned char g_zero_page[256] = {0};
+// Source of LDS-DMA copies that must deliver zeros (conv padding, rows past the end).  16 KiB: a copy may read it
+// at the channel offset of the row it stands in for (rows of up to MAD_ZERO_PAGE_BYTES - 16 bytes).
+constexpr int MAD_ZERO_PAGE_BYTES = 16384;
+__device__ __attribute__((aligned(256))) const unsigned char g_zero_page[MAD_ZERO_PAGE_BYTES] = {0};
 
 // Byte address inside the workgroup's LDS allocation of a pointer into __shared__ memory.
 __device__ __forceinline__ unsigned lds_addr(const void* p) {
