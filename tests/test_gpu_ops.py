@@ -172,6 +172,7 @@ CONV_CASES = [
     (1, 32, 192, 0, 576, 1, False, "same"),
     (2, 64, 128, 0, 128, 3, False, "same"),     # several tiles, several rows per tile
     (16, 8, 256, 0, 256, 3, False, "same"),     # few tiles, long K: the dispatcher cuts K into shares by itself
+    (3, 8, 128, 64, 128, 1, False, "same"),     # 1x1 over a concat, M = 192: a whole tile (scalar-base loader) + a partial one
 ]
 
 
@@ -435,6 +436,38 @@ def test_conv3x3_fused_projection(dev, case, dt, bn, monkeypatch):
     cpair = lambda t: t.reshape(*t.shape[:-1], Cout // 2, 2).sum(-1)      # bf16: sums per channel pair
     assert rel_err(cpair(got[..., 0]), cpair(yf.sum((1, 2)).cpu())) < 1e-4
     assert rel_err(cpair(got[..., 1]), cpair((yf * yf).sum((1, 2)).cpu())) < 1e-4
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 16, 32, 3), (1, 192, 32, 16, 2), (3, 32, 16, 16, 1), (2, 128, 48, 32, 3)])
+@pytest.mark.parametrize("fuse", [True, False])
+def test_conv_out_tap_major(dev, shape, fuse, monkeypatch):
+    """Last layer, bf16: the tap-major kernel (nine taps as the N dimension of one product per halo pixel) against
+    fp64 on the rounded operands and against the halo-tile form of the same entry point; image borders, several
+    tiles per image, 1-3 output channels, with and without the folded norm + SiLU."""
+    from mad_amd import ops
+    B, Cin, H, W_, Cout = shape
+    dt = torch.bfloat16
+    h = _rand((B, Cin, H, W_), 11)
+    wo, bo = _rand((Cout, Cin, 3, 3), 12, 0.05), _rand((Cout,), 13)
+    hq = h.to(dt).float()
+    w32 = torch.zeros(32, 3, 3, Cin)
+    w32[:Cout] = wo.permute(0, 2, 3, 1)
+    coef = torch.stack([1 + 0.3 * _rand((B, Cin), 14), 0.3 * _rand((B, Cin), 15)], dim=-1).contiguous() if fuse else None
+    hin = hq.double()
+    if fuse:
+        hin = F.silu(hin * coef[..., 0].double()[:, :, None, None] + coef[..., 1].double()[:, :, None, None])
+        hin = hin.float().to(dt).double()
+    want = F.conv2d(hin, w32[:Cout].permute(0, 3, 1, 2).to(dt).double(), bo.double(), padding=1)
+    args = (_nhwc(h, dt, dev), w32.to(dt).to(dev), bo.to(dev), Cout)
+    kw = dict(coef=None if coef is None else coef.to(dev), act=True)
+    y = ops.conv_out_fused(*args, **kw)
+    assert tuple(y.shape) == (B, Cout, H, W_)
+    # the transform's exp / reciprocal are 1-ulp instructions and its result rounds to bf16: an element of the
+    # normalised input can land on the neighbouring bf16 value
+    assert rel_err(y.cpu(), want) < (3e-3 if fuse else 2e-5)
+    monkeypatch.setenv("MAD_CONV_OUT_HALO", "1")
+    y_halo = ops.conv_out_fused(*args, **kw)
+    assert rel_err(y.cpu(), y_halo.cpu().double()) < (3e-3 if fuse else 2e-5)
 
 
 IMG8_CASES = [
