@@ -55,10 +55,11 @@ template <int TW> constexpr int halo_items() { return HS * (TW + 2) * 4; }      
 template <int TW> constexpr int halo_buf() { return (halo_items<TW>() + 63) / 64 * 64 * 16; }   // whole wave-instructions
 constexpr int CTAB_BYTES = 1024;       // one DMA instruction's worth; 256 (bf16) / 128 (fp32) bytes used
 // MFMA shape.  0: v_mfma_f32_32x32x16_bf16 everywhere; 1: v_mfma_f32_16x16x32_bf16 in the instantiations without the
-// loader transform; 2: everywhere.  (On this chip the 16x16x32 form sustains a higher clock for the same
+// loader transform; 2: also in the bf16 four-wave, 128-channel instantiations with it (the ones that fit 256
+// registers in that form); 3: everywhere.  (On this chip the 16x16x32 form sustains a higher clock for the same
 // multiplies; it issues twice as many matrix instructions, which the loader transform's vector work competes with.)
 #ifndef MAD_HALO_M16
-#define MAD_HALO_M16 1
+#define MAD_HALO_M16 2
 #endif
 // 1: the loader transform of a tap runs as one block in front of the tap's multiplies instead of in 16 pieces
 // between them (fewer registers live across the multiplies)
@@ -147,7 +148,8 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / (TW / 16) / 2) void conv3x3
     constexpr int WMH = WM / (TW / 16);            // waves stacked along the rows of one 16-column half
     static_assert(WMH >= 2 && WM % (TW / 16) == 0, "a wave covers at most 8 rows of one half");
     constexpr int TM = 8 / WMH;                    // 32-pixel accumulator tiles per wave (2 tile rows each)
-    constexpr bool M16 = MAD_HALO_M16 >= 2 || (MAD_HALO_M16 == 1 && !FUSE);
+    constexpr bool M16 = MAD_HALO_M16 >= 3 || (MAD_HALO_M16 >= 1 && !FUSE) ||
+                         (MAD_HALO_M16 == 2 && TW == 16 && TN == 2 && sizeof(T) == 2);
     constexpr int TM16 = 2 * TM, TN16 = 2 * TN;   // M16: 16-pixel (one tile row) and 16-channel fragments per wave
     constexpr int WTILE_BYTES = BN * HROW;
     constexpr int EPI_LD = BN + 4;
@@ -197,7 +199,13 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / (TW / 16) / 2) void conv3x3
     const bool last_round_real = NT * (HALO_ROUNDS - 1) + 64 * wave < HALO_BUF / 16;
     // source pixel index (b*Hs + sy)*Ws + sx of each item.  Padding / no item: -1 in the plain form (copied from the
     // zero page); in the FUSE form 0 with the item's bit set in padmask (the transform writes zeros there)
-    int src_pix[HALO_ROUNDS];
+    // (FUSE: kept as 16-bit offsets from the tile's first in-image source pixel, two per register; the tile spans at
+    // most 18 source rows, checked on the host)
+    int src_pix[FUSE ? 1 : HALO_ROUNDS];
+    unsigned rel16[FUSE ? (HALO_ROUNDS + 1) / 2 : 1] = {};
+    const int oy0 = max(ty0 - 1, 0), ox0 = max(tx0 - 1, 0);
+    const int sy0 = a.upsample ? oy0 >> 1 : oy0, sx0 = a.upsample ? ox0 >> 1 : ox0;
+    const int base_pix = (b * a.Hs + sy0) * a.Ws + sx0;            // wave-uniform
     unsigned padmask = 0;
     unsigned lchunks = 0;            // 2 bits per round: logical chunk of this thread's item
 #pragma unroll
@@ -208,7 +216,8 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / (TW / 16) / 2) void conv3x3
         const int iy = ty0 - 1 + hy, ix = tx0 - 1 + hx;
         const bool ok = item < HALO_ITEMS && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
         const int sy = a.upsample ? iy >> 1 : iy, sx = a.upsample ? ix >> 1 : ix;
-        src_pix[j] = ok ? (b * a.Hs + sy) * a.Ws + sx : (FUSE ? 0 : -1);
+        if constexpr (FUSE) rel16[j / 2] |= (unsigned)(ok ? (sy - sy0) * a.Ws + (sx - sx0) : 0) << (16 * (j & 1));
+        else src_pix[j] = ok ? (b * a.Hs + sy) * a.Ws + sx : -1;
         if (!ok) padmask |= 1u << j;
         lchunks |= (unsigned)((tid & 3) ^ ((hx >> 1) & 3)) << (2 * j);
     }
@@ -218,18 +227,18 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / (TW / 16) / 2) void conv3x3
     constexpr int XPAIRS = VEC / 2;
     constexpr int LAST_REAL = HALO_ITEMS - NT * (HALO_ROUNDS - 1);
     constexpr bool MINI = FUSE && HALO_ROUNDS > 1 && LAST_REAL * XPAIRS <= 64;
-    int mini_off = 0, mini_cf = 0;       // byte offset of this lane's pair in a halo buffer; float offset of its (a, d) pairs
-    bool mini_on = false, mini_pad = false;
-    if constexpr (MINI) {
+    // (its per-lane addresses and flags are worked out where they are used, once per chunk, rather than kept in
+    // registers through the loop)
+    auto mini_geom = [&](int& off, int& cf, bool& on, bool& pad) {
         const int it = NT * (HALO_ROUNDS - 1) + lane / XPAIRS, pr = lane % XPAIRS;
         const int p = it >> 2;
         const int hy = p / HSX, hx = p - hy * HSX;
         const int iy = ty0 - 1 + hy, ix = tx0 - 1 + hx;
-        mini_on = wave == 0 && lane < LAST_REAL * XPAIRS;
-        mini_pad = !(iy >= 0 && iy < a.H && ix >= 0 && ix < a.W);
-        mini_off = it * 16 + pr * (16 / XPAIRS);
-        mini_cf = (((it & 3) ^ ((hx >> 1) & 3)) * VEC + 2 * pr) * 2;
-    }
+        on = wave == 0 && lane < LAST_REAL * XPAIRS;
+        pad = !(iy >= 0 && iy < a.H && ix >= 0 && ix < a.W);
+        off = it * 16 + pr * (16 / XPAIRS);
+        cf = (((it & 3) ^ ((hx >> 1) & 3)) * VEC + 2 * pr) * 2;
+    };
     const unsigned halo_base = lds_addr(halo0);
     const unsigned sink_base = lds_addr(sink0);
     auto dma_item = [&](int cc, int j, int buf) {
@@ -237,14 +246,19 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / (TW / 16) / 2) void conv3x3
         const T* src; int cs, coff;
         if (c0 < a.C1) { src = (const T*)a.x1; cs = a.C1; coff = c0; }
         else { src = (const T*)a.x2; cs = a.C2; coff = c0 - a.C1; }
-        const int lc = (lchunks >> (2 * j)) & 3;
+        unsigned lcs = lchunks;
+        asm volatile("" : "+v"(lcs));
+        const int lc = (lcs >> (2 * j)) & 3;
         const bool sink = j == HALO_ROUNDS - 1 && !last_round_real;     // wave-uniform
         const unsigned dst = sink ? sink_base : halo_base + buf * HALO_BUF + (NT * j + 64 * wave) * 16;
         if constexpr (FUSE) {
             // scalar base = the source's channel chunk, 32-bit lane offset = pixel and logical chunk (pixel index
             // and row pitch both below 2^24; the tensor below 4 GB: checked on the host)
-            const unsigned off = (__umul24((unsigned)src_pix[j], (unsigned)cs) + lc * VEC) * (unsigned)sizeof(T);
-            glds16s(src + coff, off, __builtin_amdgcn_readfirstlane(dst));
+            unsigned packed = rel16[j / 2];
+            asm volatile("" : "+v"(packed));      // unpacked where it is used, not once per round ahead of the loop
+            const unsigned rel = (packed >> (16 * (j & 1))) & 0xffffu;
+            const unsigned off = (__umul24(rel, (unsigned)cs) + lc * VEC) * (unsigned)sizeof(T);
+            glds16s(src + coff + (size_t)base_pix * cs, off, __builtin_amdgcn_readfirstlane(dst));
         } else {
             const T* p = src + (size_t)max(src_pix[j], 0) * cs + coff + lc * VEC;
             const void* g = src_pix[j] >= 0 ? (const void*)p : (const void*)g_zero_page;
@@ -263,6 +277,8 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / (TW / 16) / 2) void conv3x3
     const float xk1 = a.act ? -1.44269504088896340736f : 0.0f, xk0 = a.act ? 0.0f : -200.0f;
     // in-place y = act(x*a + d) of this lane's element pair of the last round (MINI), zeros for padding
     auto xform_mini = [&](int buf) {
+        int mini_off, mini_cf; bool mini_on, mini_pad;
+        mini_geom(mini_off, mini_cf, mini_on, mini_pad);
         unsigned char* addr = halo0 + buf * HALO_BUF + mini_off;
         const float4 ad = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(ctab0 + buf * CTAB_BYTES) + mini_cf);
         float f0, f1;
@@ -296,13 +312,15 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / (TW / 16) / 2) void conv3x3
     // the slots XSTRIDE*p .. XSTRIDE*p+3: unpack + multiply-add, exp, reciprocal + product, pack.  The item and
     // the first coefficient pair are requested at the top of the tap; each later coefficient pair one pair ahead.
     constexpr int XSTRIDE = 16 / XPAIRS;
-    uint4 xraw; float4 xcf[2]; float xt[2], xu[2]; unsigned xout[4];
+    uint4 xraw; float4 xcf[1]; float xt[2], xu[2]; unsigned xout[4];
     const unsigned char* xaddr = nullptr; const float* xcoef = nullptr;
     auto xf_begin = [&](int j, int buf) {
         const int item = tid + NT * j;
         xaddr = halo0 + buf * HALO_BUF + item * 16;
         xraw = *reinterpret_cast<const uint4*>(xaddr);
-        const int lc = (lchunks >> (2 * j)) & 3;
+        unsigned lcs = lchunks;
+        asm volatile("" : "+v"(lcs));
+        const int lc = (lcs >> (2 * j)) & 3;
         xcoef = reinterpret_cast<const float*>(ctab0 + buf * CTAB_BYTES) + lc * VEC * 2;
         xcf[0] = *reinterpret_cast<const float4*>(xcoef);
     };
@@ -314,8 +332,7 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / (TW / 16) / 2) void conv3x3
             float f0, f1;
             if (sizeof(T) == 2) { f0 = __uint_as_float(w[pr] << 16); f1 = __uint_as_float(w[pr] & 0xffff0000u); }
             else { f0 = __uint_as_float(w[2 * pr]); f1 = __uint_as_float(w[2 * pr + 1]); }
-            const float4 ad = xcf[pr & 1];
-            if (pr + 1 < XPAIRS) xcf[(pr + 1) & 1] = *reinterpret_cast<const float4*>(xcoef + 4 * (pr + 1));
+            const float4 ad = xcf[0];
             // one-element instructions on purpose (fma1 / div2): left to itself the compiler pairs these into
             // v_pk_fma_f32 / v_pk_mul_f32, which needs three register moves per pair to line up (a0, a1) and
             // (d0, d1) from the interleaved table and, issued beside MFMAs, costs more than the two plain ones
@@ -324,6 +341,8 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / (TW / 16) / 2) void conv3x3
             // reciprocal 1, the product t itself): no select on the way
             xu[0] = fma1(xt[0], xk1, xk0); xu[1] = fma1(xt[1], xk1, xk0);
         } else if (k == 1) {
+            // the next pair's coefficients are requested into the registers the multiply-adds have just read
+            if (pr + 1 < XPAIRS) xcf[0] = *reinterpret_cast<const float4*>(xcoef + 4 * (pr + 1));
             xu[0] = 1.0f + __builtin_amdgcn_exp2f(xu[0]); xu[1] = 1.0f + __builtin_amdgcn_exp2f(xu[1]);
         } else if (k == 2) {
             div2(xt[0], xt[1], xu[0], xu[1]);
@@ -346,6 +365,8 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / (TW / 16) / 2) void conv3x3
 
     // The one-pair form of the last round (MINI), stages in slots 0..3
     auto xm_begin = [&](int buf) {
+        int mini_off, mini_cf; bool mini_on, mini_pad;
+        mini_geom(mini_off, mini_cf, mini_on, mini_pad);
         xaddr = halo0 + buf * HALO_BUF + mini_off;
         if (sizeof(T) == 2) xraw.x = *reinterpret_cast<const unsigned*>(xaddr);
         else { const uint2 w = *reinterpret_cast<const uint2*>(xaddr); xraw.x = w.x; xraw.y = w.y; }
@@ -364,6 +385,8 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / (TW / 16) / 2) void conv3x3
         } else if (k == 2) {
             div2(xt[0], xt[1], xu[0], xu[1]);
         } else if (k == 3) {
+            int mini_off, mini_cf; bool mini_on, mini_pad;
+            mini_geom(mini_off, mini_cf, mini_on, mini_pad);
             if (mini_pad) { xt[0] = 0.0f; xt[1] = 0.0f; }
             if (mini_on) {
                 if (sizeof(T) == 2) {
@@ -966,9 +989,10 @@ static int conv3x3_fused_impl(const void* x1, int C1, const void* x2, int C2, co
                 "mad_conv3x3_fused: H=%d, W=%d must be multiples of 16", H, W);
     MAD_REQUIRE((size_t)B * H * W < (1u << 31), "mad_conv3x3_fused: tensor too large for 32-bit pixel indices");
     // the loader-transform form addresses its input with 24-bit pixel indices and 32-bit byte offsets
-    MAD_REQUIRE(!coef || ((size_t)B * H * W < (1u << 24) && (size_t)B * H * W * (C1 > C2 ? C1 : C2) * 4 < ((size_t)1 << 32)),
-                "mad_conv3x3_fused: input of B*H*W = %zu pixels is too large for the fused loader (split the batch)",
-                (size_t)B * H * W);
+    // the loader-transform form addresses a tile's input pixels with 16-bit offsets from the tile's first pixel (18
+    // rows of the image) and 32-bit byte offsets
+    MAD_REQUIRE(!coef || (W < 3600 && (size_t)18 * W * (C1 > C2 ? C1 : C2) * 4 < ((size_t)1 << 32)),
+                "mad_conv3x3_fused: rows of W = %d pixels are too long for the fused loader", W);
     MAD_REQUIRE(res_mode >= MAD_RES_NONE && res_mode <= MAD_RES_DOWN && (res_mode == MAD_RES_NONE || residual),
                 "mad_conv3x3_fused: bad residual mode %d", res_mode);
     HaloArgs a;
