@@ -1029,8 +1029,9 @@ static int conv3x3_fused_impl(const void* x1, int C1, const void* x2, int C2, co
     // image is wide enough and such tiles still fill the chip; 16 x 16 tiles on four waves otherwise
     const bool wide_fits = dtype == MAD_BF16 && !gn && W % 32 == 0;
     // (measured: a gain of 3-4 % for layers of 256 and more output channels, a loss of 2-3 % at 128, whose
-    // workgroups then have no second workgroup on their CU to overlap their first and last phases with)
-    bool wide_ok = wide_fits && Cout >= 256 && B * (W / 32) * a.tiles_y * (Cout / 128) >= 256;
+    // workgroups then have no second workgroup on their CU to overlap their first and last phases with; with the
+    // loader transform the four-wave form on the 16x16x32 MFMA is now 1-4 % ahead at every size)
+    bool wide_ok = wide_fits && !coef && Cout >= 256 && B * (W / 32) * a.tiles_y * (Cout / 128) >= 256;
     if (const char* f = getenv("MAD_HALO_WIDE"))              // tuning / test aid: 0 = never, 2 = wherever it fits
         wide_ok = atoi(f) == 2 ? wide_fits : (wide_ok && atoi(f) != 0);
     auto run = [&](bool narrow) -> int {
