@@ -179,9 +179,26 @@ int mad_conv2d_ws(const void* x1, int C1, const void* x2, int C2, const void* w,
  *   (the GroupNorm that consumes them must have an even number of channels per group, as every
  *   GroupNorm of the reference has: model.py:174-181).
  * x is the concatenation of x1 (C1) and x2 (C2), NHWC at (H,W), or at (H/2,W/2) when `upsample`.
- * C1, C2 multiples of 32 (bf16) / 16 (fp32).  act: 0 none, 1 SiLU.
+ * C1, C2 multiples of 32 (bf16) / 16 (fp32).
+ * act is a set of bits:
+ *   MAD_ACT_SILU       act = SiLU (otherwise the identity);
+ *   MAD_ACT_PRESCALED  (with coef and MAD_ACT_SILU) coef holds -log2(e) * (a, d), as mad_gn_finalize_scaled writes
+ *                      it with scale = MAD_PRESCALE_COEF, and w holds MAD_PRESCALE_W * the layer's weights: the
+ *                      loader then computes u = x*a' + d' and u / (1 + 2^u) = -log2(e) * silu(x*a + d), one
+ *                      multiply-add per input element less, and the product with the scaled weights is the same
+ *                      convolution (the 1x1 projection weights of mad_conv3x3_fused_skip stay unscaled);
+ *   MAD_W_TILED        w is stored tile by tile instead of (Cout,3,3,Cin): with CK = 32 (bf16) / 16 (fp32)
+ *                      channels per 64-byte chunk, the 1 KiB block [n/16][c/CK][tap] holds rows n%16 of 64 bytes,
+ *                      and inside a row the 16-byte piece at position p holds channels
+ *                      c0 + ((p ^ (-((n%16)/4) & 3)) * CK/4 ...) of the chunk starting at c0 -- the order the kernel
+ *                      keeps a weight tile in LDS, so every copy of it reads 1 KiB in one piece.
  * Replaces GroupNorm -> SiLU -> Conv2d (model.py:341, 346-350) and the statistics pass of the
  * GroupNorm that follows (model.py:182-190). */
+#define MAD_ACT_SILU 1
+#define MAD_ACT_PRESCALED 2
+#define MAD_W_TILED 4
+#define MAD_PRESCALE_COEF (-1.44269504088896340736f) /* -log2(e) */
+#define MAD_PRESCALE_W (-0.69314718055994530942f)    /* -ln(2) */
 int mad_conv3x3_fused(const void* x1, int C1, const void* x2, int C2, const float* coef, int act,
                       const void* w, const float* bias, const void* residual, int res_mode, void* y,
                       float* stats, int dtype, int B, int H, int W, int Cout, int upsample,
@@ -229,6 +246,13 @@ int mad_gn_partial(const void* x1, int C1, const void* x2, int C2, int dtype, fl
 int mad_gn_finalize(const float* partial1, int C1, int nsplit1, const float* partial2, int C2,
                     int nsplit2, const float* gamma, const float* beta, const float* ada,
                     int ada_stride, float* coef, int B, int groups, int HW, float eps, void* stream);
+/* mad_gn_finalize with every (a, d) pair multiplied by `scale` as it is written (scale = 1: the same values).
+ * With MAD_PRESCALE_COEF the table feeds mad_conv3x3_fused in its MAD_ACT_PRESCALED form.  Same reference
+ * lines as mad_gn_finalize. */
+int mad_gn_finalize_scaled(const float* partial1, int C1, int nsplit1, const float* partial2, int C2,
+                           int nsplit2, const float* gamma, const float* beta, const float* ada,
+                           int ada_stride, float* coef, int B, int groups, int HW, float eps, float scale,
+                           void* stream);
 
 /* GroupNorm coefficients in ONE call that allocates nothing: mad_gn_partial followed by mad_gn_finalize with
  * the partial-sum slab between them held in a device array inside the library (8 MiB per GPU, kept until the

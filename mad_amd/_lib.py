@@ -17,6 +17,10 @@ ALGO_DDPM, ALGO_DDIM = 0, 1
 PRED_EPSILON, PRED_SAMPLE, PRED_V = 0, 1, 2
 OP_STEP, OP_COMPUTE_EPS, OP_INVERSE = 0, 1, 2
 RES_NONE, RES_SAME, RES_UP, RES_DOWN = 0, 1, 2, 3
+# bits of the `act` argument of mad_conv3x3_fused / _skip, and the factors of its prescaled form
+ACT_SILU, ACT_PRESCALED, W_TILED = 1, 2, 4
+PRESCALE_COEF = -1.4426950408889634      # -log2(e): (a, d) as mad_gn_finalize_scaled writes them
+PRESCALE_W = -0.6931471805599453         # -ln(2): the weights
 
 
 class SamplerCoef(Structure):
@@ -90,6 +94,8 @@ SIGNATURES = {
     "mad_gn_partial": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
     "mad_gn_finalize": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int,
                                 c_void_p, c_int, c_int, c_int, c_float, c_void_p]),
+    "mad_gn_finalize_scaled": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int,
+                                       c_void_p, c_int, c_int, c_int, c_float, c_float, c_void_p]),
     "mad_gn_coef_static_max_floats": (ctypes.c_size_t, []),
     "mad_gn_coef_static": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
                                    c_int, c_int, c_int, c_float, c_void_p]),

@@ -38,6 +38,7 @@ struct HaloArgs {
     const void* sx1; const void* sx2; const void* sw;
     int SC1, SC2;
     int stream_out;   // output larger than the on-die caches: written with streaming stores
+    int wtiled;       // w is in the tiled layout (see mad_conv3x3_fused): every weight copy reads 1 KiB in one piece
     // GSTAT form: the output is the gradient dy reaching h = act(GroupNorm([gx1, gx2]) (affine in gcoef)), possibly
     // dropped out (gdm); `stats` then receives that GroupNorm backward's partial sums (sum g, sum g*x) per tile,
     // g = dy * keep * act'(a*x + d), instead of the output's own statistics.
@@ -135,8 +136,11 @@ template <int BN, int TW> constexpr int halo_lds_bytes() {
 }
 
 // OUT_NCHW: write the first a.Cout (<= BN) channels as NCHW fp32 with bias (last layer).
-template <typename T, bool FUSE, int WM, int WN, int TN, bool OUT_NCHW, bool SKIP, bool GSTAT, int TW = 16>
+// PRE: the coefficient table holds (a, d) * -log2(e) and the weights carry a factor -ln(2): the loader computes
+// u = x*a' + d' and u / (1 + 2^u), which is -log2(e) * silu(x*a + d), one multiply-add per element less.
+template <typename T, bool FUSE, int WM, int WN, int TN, bool OUT_NCHW, bool SKIP, bool GSTAT, int TW = 16, bool PRE = false>
 __global__ __launch_bounds__(64 * WM * WN, WM * WN / (TW / 16) / 2) void conv3x3_halo_kernel(HaloArgs a) {
+    static_assert(!PRE || (FUSE && !OUT_NCHW && !GSTAT), "the prescaled form belongs to the loader transform");
     constexpr int NWAVES = WM * WN, NT = 64 * NWAVES;
     static_assert(NWAVES == 4 || NWAVES == 8, "4 or 8 waves");
     static_assert(TW == 16 || TW == 32, "tile width");
@@ -181,6 +185,8 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / (TW / 16) / 2) void conv3x3
 
     const int Ctot = a.C1 + a.C2;
     const int nchunks = Ctot / CK;
+    // tiles away from the image border have no padding in their halo: their transform skips the zeroing selects
+    const bool tile_pad = ty0 == 0 || tx0 == 0 || ty0 + HT >= a.H || tx0 + TW >= a.W;
 #ifdef MAD_HALO_STAMPS
     unsigned* const stamp_lds = reinterpret_cast<unsigned*>(smem + halo_lds_bytes<BN, TW>() - 4096);
     const bool stamp_on = blockIdx.x == gridDim.x / 2 + 3;
@@ -275,6 +281,8 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / (TW / 16) / 2) void conv3x3
     // exponent of the sigmoid: -t*log2(e) with the activation, -200 without it (exp2 gives 0, the reciprocal
     // 1, the product t itself): no select on the way
     const float xk1 = a.act ? -1.44269504088896340736f : 0.0f, xk0 = a.act ? 0.0f : -200.0f;
+    // denominator 1 + 2^u of the sigmoid from t = x*a + d (PRE: t already is the exponent)
+    auto sig_den = [&](float t) { return 1.0f + __builtin_amdgcn_exp2f(PRE ? t : fma1(t, xk1, xk0)); };
     // in-place y = act(x*a + d) of this lane's element pair of the last round (MINI), zeros for padding
     auto xform_mini = [&](int buf) {
         int mini_off, mini_cf; bool mini_on, mini_pad;
@@ -290,8 +298,7 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / (TW / 16) / 2) void conv3x3
             f0 = w.x; f1 = w.y;
         }
         float t0 = fma1(f0, ad.x, ad.y), t1 = fma1(f1, ad.z, ad.w);
-        const float u0 = 1.0f + __builtin_amdgcn_exp2f(fma1(t0, xk1, xk0));
-        const float u1 = 1.0f + __builtin_amdgcn_exp2f(fma1(t1, xk1, xk0));
+        const float u0 = sig_den(t0), u1 = sig_den(t1);
         div2(t0, t1, u0, u1);
         if (mini_pad) { t0 = 0.0f; t1 = 0.0f; }
         if (mini_on) {
@@ -338,12 +345,12 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / (TW / 16) / 2) void conv3x3
             // (d0, d1) from the interleaved table and, issued beside MFMAs, costs more than the two plain ones
             xt[0] = fma1(f0, ad.x, ad.y); xt[1] = fma1(f1, ad.z, ad.w);
             // exponent of the sigmoid: -t*log2(e) with the activation, -200 without it (exp2 gives 0, the
-            // reciprocal 1, the product t itself): no select on the way
-            xu[0] = fma1(xt[0], xk1, xk0); xu[1] = fma1(xt[1], xk1, xk0);
+            // reciprocal 1, the product t itself): no select on the way.  PRE: t is the exponent already.
+            if (!PRE) { xu[0] = fma1(xt[0], xk1, xk0); xu[1] = fma1(xt[1], xk1, xk0); }
         } else if (k == 1) {
             // the next pair's coefficients are requested into the registers the multiply-adds have just read
             if (pr + 1 < XPAIRS) xcf[0] = *reinterpret_cast<const float4*>(xcoef + 4 * (pr + 1));
-            xu[0] = 1.0f + __builtin_amdgcn_exp2f(xu[0]); xu[1] = 1.0f + __builtin_amdgcn_exp2f(xu[1]);
+            xu[0] = 1.0f + __builtin_amdgcn_exp2f(PRE ? xt[0] : xu[0]); xu[1] = 1.0f + __builtin_amdgcn_exp2f(PRE ? xt[1] : xu[1]);
         } else if (k == 2) {
             div2(xt[0], xt[1], xu[0], xu[1]);
         } else {
@@ -354,8 +361,8 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / (TW / 16) / 2) void conv3x3
                 xout[pr] = __builtin_bit_cast(unsigned, __builtin_convertvector(v2, bf16x2_t));
             } else { xout[2 * pr] = __float_as_uint(xt[0]); xout[2 * pr + 1] = __float_as_uint(xt[1]); }
             if (pr == XPAIRS - 1) {
-                const bool pad = (padmask >> j) & 1;
-                uint4 o = make_uint4(pad ? 0u : xout[0], pad ? 0u : xout[1], pad ? 0u : xout[2], pad ? 0u : xout[3]);
+                uint4 o = make_uint4(xout[0], xout[1], xout[2], xout[3]);
+                if (tile_pad && ((padmask >> j) & 1)) o = make_uint4(0u, 0u, 0u, 0u);
                 const int item = tid + NT * j;
                 if (j < HALO_ROUNDS - 1 || item < HALO_ITEMS)
                     *reinterpret_cast<uint4*>(const_cast<unsigned char*>(xaddr)) = o;
@@ -379,9 +386,9 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / (TW / 16) / 2) void conv3x3
             else { f0 = __uint_as_float(xraw.x); f1 = __uint_as_float(xraw.y); }
             const float4 ad = xcf[0];
             xt[0] = fma1(f0, ad.x, ad.y); xt[1] = fma1(f1, ad.z, ad.w);
-            xu[0] = fma1(xt[0], xk1, xk0); xu[1] = fma1(xt[1], xk1, xk0);
+            if (!PRE) { xu[0] = fma1(xt[0], xk1, xk0); xu[1] = fma1(xt[1], xk1, xk0); }
         } else if (k == 1) {
-            xu[0] = 1.0f + __builtin_amdgcn_exp2f(xu[0]); xu[1] = 1.0f + __builtin_amdgcn_exp2f(xu[1]);
+            xu[0] = 1.0f + __builtin_amdgcn_exp2f(PRE ? xt[0] : xu[0]); xu[1] = 1.0f + __builtin_amdgcn_exp2f(PRE ? xt[1] : xu[1]);
         } else if (k == 2) {
             div2(xt[0], xt[1], xu[0], xu[1]);
         } else if (k == 3) {
@@ -411,15 +418,20 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / (TW / 16) / 2) void conv3x3
         const int blk = (j * NWAVES + wave) % (BN / 16);   // 16-row block index
         const int r = blk * 16 + (lane >> 2);
         const int lchunk = (lane & 3) ^ ((-(r >> 2)) & 3);
-        wrow_off[j] = (unsigned)((r * 9 * Ctot + lchunk * VEC) * (int)sizeof(T));
+        wrow_off[j] = a.wtiled ? (unsigned)lane * 16u : (unsigned)((r * 9 * Ctot + lchunk * VEC) * (int)sizeof(T));
     }
     auto stage_w = [&](int cc, int tap, int buf) {
-        // scalar base = first row of this workgroup's channels at (tap, chunk); the lane offset never changes
+        // scalar base = first row of this workgroup's channels at (tap, chunk); the lane offset never changes.
+        // Tiled weights: the 16 rows x 64 bytes of a copy are one KiB, already in LDS order, at
+        // [16-row block][chunk][tap]: scalar base = that KiB, lane offset = lane * 16.
         const T* base = (const T*)a.w + ((size_t)n0 * 9 + tap) * Ctot + cc * CK;
 #pragma unroll
         for (int j = 0; j < NW; ++j) {
             const int blk = (j * NWAVES + wave) % (BN / 16);
-            glds16s(base, wrow_off[j], __builtin_amdgcn_readfirstlane(wt_base + buf * WTILE_BYTES + blk * 16 * HROW));
+            const void* bj = a.wtiled ? (const void*)((const unsigned char*)a.w +
+                                                      (((size_t)(n0 / 16 + blk) * nchunks + cc) * 9 + tap) * (16 * HROW))
+                                      : (const void*)base;
+            glds16s(bj, wrow_off[j], __builtin_amdgcn_readfirstlane(wt_base + buf * WTILE_BYTES + blk * 16 * HROW));
         }
     };
 
@@ -446,20 +458,29 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / (TW / 16) / 2) void conv3x3
 
     f32x16 acc[M16 ? 1 : TM][M16 ? 1 : TN];
     f32x4 acc16[M16 ? TM16 : 1][M16 ? TN16 : 1];
+    // The accumulators start from the bias of their channels (the epilogue then has nothing to add); the NCHW form
+    // adds it when it writes.  Register e of a lane: M16 channel 16*j + 4*fh + e; 32x32: 32*j + 8*(e/4) + 4*fh + e%4.
+    const bool bias_init = !OUT_NCHW && a.bias != nullptr;
     if constexpr (M16) {
 #pragma unroll
-        for (int i = 0; i < TM16; ++i)
+        for (int j = 0; j < TN16; ++j) {
+            f32x4 b4 = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (bias_init) b4 = *reinterpret_cast<const f32x4*>(a.bias + n0 + wn * (TN * 32) + j * 16 + 4 * fh);
 #pragma unroll
-            for (int j = 0; j < TN16; ++j)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc16[i][j][e] = 0.0f;
+            for (int i = 0; i < TM16; ++i) acc16[i][j] = b4;
+        }
     } else {
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
+            for (int g4 = 0; g4 < 4; ++g4) {
+                f32x4 b4 = {0.0f, 0.0f, 0.0f, 0.0f};
+                if (bias_init) b4 = *reinterpret_cast<const f32x4*>(a.bias + n0 + wn * (TN * 32) + j * 32 + 8 * g4 + 4 * fh);
 #pragma unroll
-                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[i][j][4 * g4 + e] = b4[e];
+            }
     }
 
     // ---- prologue: the whole halo of chunk 0, its coefficients, weight tiles 0 and 1
@@ -495,8 +516,7 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / (TW / 16) / 2) void conv3x3
             for (int q = 0; q < XPAIRS; ++q) {
                 const float4 ad = cfr[j & 1][q];
                 float t0 = fma1(f[2 * q], ad.x, ad.y), t1 = fma1(f[2 * q + 1], ad.z, ad.w);
-                const float u0 = 1.0f + __builtin_amdgcn_exp2f(fma1(t0, xk1, xk0));
-                const float u1 = 1.0f + __builtin_amdgcn_exp2f(fma1(t1, xk1, xk0));
+                const float u0 = sig_den(t0), u1 = sig_den(t1);
                 div2(t0, t1, u0, u1);
                 f[2 * q] = t0; f[2 * q + 1] = t1;
             }
@@ -777,9 +797,9 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / (TW / 16) / 2) void conv3x3
     constexpr int CPR = BN / VEC;            // 16-byte chunks per output row
     constexpr int RPP = NT / CPR;            // rows per pass
     const int er = tid / CPR, ec = (tid % CPR) * VEC;
-    float bias_v[VEC], ssum[VEC], ssq[VEC];
+    float ssum[VEC], ssq[VEC];
 #pragma unroll
-    for (int i = 0; i < VEC; ++i) { bias_v[i] = a.bias ? a.bias[n0 + ec + i] : 0.0f; ssum[i] = 0.0f; ssq[i] = 0.0f; }
+    for (int i = 0; i < VEC; ++i) { ssum[i] = 0.0f; ssq[i] = 0.0f; }
     const T* res = (const T*)a.residual;
     T* y = (T*)a.y;
     constexpr int RPT = 128 / RPP;           // rows per thread per pass
@@ -815,8 +835,7 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / (TW / 16) / 2) void conv3x3
 #pragma unroll
             for (int i = 0; i < VEC; i += 4) {
                 const float4 t = *reinterpret_cast<const float4*>(ctile + r * EPI_LD + ec + i);
-                v[i] = t.x + bias_v[i]; v[i + 1] = t.y + bias_v[i + 1];
-                v[i + 2] = t.z + bias_v[i + 2]; v[i + 3] = t.w + bias_v[i + 3];
+                v[i] = t.x; v[i + 1] = t.y; v[i + 2] = t.z; v[i + 3] = t.w;      // the bias is in the accumulators
             }
             if (a.res_mode == MAD_RES_SAME || a.res_mode == MAD_RES_UP) {
                 Vec16<T> rv; rv.raw = rpre[k];
@@ -948,17 +967,18 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / (TW / 16) / 2) void conv3x3
 #endif
 }
 
-template <typename T, bool FUSE, int WM, int WN, int TN, bool OUT_NCHW, bool SKIP = false, bool GSTAT = false, int TW = 16>
+template <typename T, bool FUSE, int WM, int WN, int TN, bool OUT_NCHW, bool SKIP = false, bool GSTAT = false, int TW = 16,
+          bool PRE = false>
 static int launch_halo(const HaloArgs& a0, hipStream_t s, const char* what) {
     constexpr int lds = halo_lds_bytes<WN * TN * 32, TW>();
     static int lds_dev = -1;
-    MAD_REQUIRE(raise_lds_limit(reinterpret_cast<const void*>(&conv3x3_halo_kernel<T, FUSE, WM, WN, TN, OUT_NCHW, SKIP, GSTAT, TW>),
+    MAD_REQUIRE(raise_lds_limit(reinterpret_cast<const void*>(&conv3x3_halo_kernel<T, FUSE, WM, WN, TN, OUT_NCHW, SKIP, GSTAT, TW, PRE>),
                                 lds, &lds_dev),
                 "%s: cannot raise the dynamic LDS limit to %d", what, lds);
     HaloArgs a = a0;
     a.tiles_x = a.W / TW;
     const int grid = a.B * a.tiles_x * a.tiles_y * a.ntiles_n;
-    hipLaunchKernelGGL((conv3x3_halo_kernel<T, FUSE, WM, WN, TN, OUT_NCHW, SKIP, GSTAT, TW>), dim3(grid), dim3(64 * WM * WN), lds, s, a);
+    hipLaunchKernelGGL((conv3x3_halo_kernel<T, FUSE, WM, WN, TN, OUT_NCHW, SKIP, GSTAT, TW, PRE>), dim3(grid), dim3(64 * WM * WN), lds, s, a);
     return check_launch(what);
 }
 
@@ -995,11 +1015,15 @@ static int conv3x3_fused_impl(const void* x1, int C1, const void* x2, int C2, co
                 "mad_conv3x3_fused: rows of W = %d pixels are too long for the fused loader", W);
     MAD_REQUIRE(res_mode >= MAD_RES_NONE && res_mode <= MAD_RES_DOWN && (res_mode == MAD_RES_NONE || residual),
                 "mad_conv3x3_fused: bad residual mode %d", res_mode);
+    // act: bit 0 SiLU, bit 1 prescaled coefficients and weights, bit 2 tiled weight layout
+    MAD_REQUIRE(act >= 0 && act < 8 && (!(act & MAD_ACT_PRESCALED) || (coef && (act & MAD_ACT_SILU))),
+                "mad_conv3x3_fused: act=%d: the prescaled form needs coef and SiLU", act);
+    const bool pre = act & MAD_ACT_PRESCALED;
     HaloArgs a;
     a.x1 = x1; a.x2 = C2 ? x2 : x1; a.w = w; a.bias = bias; a.coef = coef; a.residual = residual; a.y = y;
     a.stats = stats;
     a.C1 = C1; a.C2 = C2; a.B = B; a.H = H; a.W = W; a.Cout = Cout; a.upsample = upsample; a.res_mode = res_mode;
-    a.act = act;
+    a.act = act & MAD_ACT_SILU; a.wtiled = (act & MAD_W_TILED) != 0;
     a.Hs = upsample ? H / 2 : H; a.Ws = upsample ? W / 2 : W;
     a.tiles_x = W / HT; a.tiles_y = H / HT;
     a.sx1 = sx1; a.sx2 = SC2 ? sx2 : sx1; a.sw = sw; a.SC1 = SC1; a.SC2 = SC2;
@@ -1027,7 +1051,7 @@ static int conv3x3_fused_impl(const void* x1, int C1, const void* x2, int C2, co
     }
     // 16 x 32 pixel tiles on eight waves (one workgroup per CU, half the weight copies per multiply) where the
     // image is wide enough and such tiles still fill the chip; 16 x 16 tiles on four waves otherwise
-    const bool wide_fits = dtype == MAD_BF16 && !gn && W % 32 == 0;
+    const bool wide_fits = dtype == MAD_BF16 && !gn && !pre && W % 32 == 0;
     // (measured: a gain of 3-4 % for layers of 256 and more output channels, a loss of 2-3 % at 128, whose
     // workgroups then have no second workgroup on their CU to overlap their first and last phases with; with the
     // loader transform the four-wave form on the 16x16x32 MFMA is now 1-4 % ahead at every size)
@@ -1045,9 +1069,12 @@ static int conv3x3_fused_impl(const void* x1, int C1, const void* x2, int C2, co
 #define MAD_HALO_DISPATCH(T_, TN_)                                                                    \
     do {                                                                                              \
         if (gn) return launch_halo<T_, false, 2, 2, TN_, false, false, true>(a, s, what);             \
-        if (SC1 > 0)                                                                                  \
+        if (SC1 > 0) {                                                                                \
+            if (pre) return launch_halo<T_, true, 2, 2, TN_, false, true, false, 16, true>(a, s, what); \
             return coef ? launch_halo<T_, true, 2, 2, TN_, false, true>(a, s, what)                   \
                         : launch_halo<T_, false, 2, 2, TN_, false, true>(a, s, what);                 \
+        }                                                                                             \
+        if (pre) return launch_halo<T_, true, 2, 2, TN_, false, false, false, 16, true>(a, s, what);  \
         return coef ? launch_halo<T_, true, 2, 2, TN_, false>(a, s, what)                             \
                     : launch_halo<T_, false, 2, 2, TN_, false>(a, s, what);                           \
     } while (0)
@@ -1123,7 +1150,7 @@ extern "C" int mad_conv_out_fused(const void* x, int Cin, const float* coef, int
     a.x1 = x; a.x2 = x; a.w = w; a.bias = bias; a.coef = coef; a.residual = nullptr; a.y = y; a.stats = nullptr;
     a.C1 = Cin; a.C2 = 0; a.B = B; a.H = H; a.W = W; a.Cout = Cout; a.upsample = 0; a.res_mode = MAD_RES_NONE;
     a.act = act; a.Hs = H; a.Ws = W;
-    a.sx1 = a.sx2 = a.sw = nullptr; a.SC1 = a.SC2 = 0; a.stream_out = 0;
+    a.sx1 = a.sx2 = a.sw = nullptr; a.SC1 = a.SC2 = 0; a.stream_out = 0; a.wtiled = 0;
     a.tiles_x = W / HT; a.tiles_y = H / HT; a.ntiles_n = 1; a.n_off = 0;
     hipStream_t s = (hipStream_t)stream;
     const char* what = "mad_conv_out_fused";

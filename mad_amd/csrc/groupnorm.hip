@@ -84,7 +84,8 @@ __global__ __launch_bounds__(64 * NWV) void gn_finalize_kernel(const float* __re
                                                           const float* __restrict__ gamma,
                                                           const float* __restrict__ beta,
                                                           const float* __restrict__ ada, int ada_stride,
-                                                          float* __restrict__ coef, int groups, int HW, float eps) {
+                                                          float* __restrict__ coef, int groups, int HW, float eps,
+                                                          float out_scale) {
     constexpr int NT = 64 * NWV;
     const int g = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;       // lane: index in the workgroup
     const int C = C1 + C2, cpg = C / groups;
@@ -136,8 +137,8 @@ __global__ __launch_bounds__(64 * NWV) void gn_finalize_kernel(const float* __re
             a = a * sc;
             d = fmaf(d, sc, sh);
         }
-        coef[((size_t)b * C + c) * 2] = a;
-        coef[((size_t)b * C + c) * 2 + 1] = d;
+        coef[((size_t)b * C + c) * 2] = a * out_scale;
+        coef[((size_t)b * C + c) * 2 + 1] = d * out_scale;
     }
 }
 
@@ -248,6 +249,14 @@ extern "C" int mad_gn_partial(const void* x1, int C1, const void* x2, int C2, in
 extern "C" int mad_gn_finalize(const float* partial1, int C1, int nsplit1, const float* partial2, int C2, int nsplit2,
                                const float* gamma, const float* beta, const float* ada, int ada_stride, float* coef,
                                int B, int groups, int HW, float eps, void* stream) {
+    return mad_gn_finalize_scaled(partial1, C1, nsplit1, partial2, C2, nsplit2, gamma, beta, ada, ada_stride, coef, B,
+                                  groups, HW, eps, 1.0f, stream);
+}
+
+extern "C" int mad_gn_finalize_scaled(const float* partial1, int C1, int nsplit1, const float* partial2, int C2,
+                                      int nsplit2, const float* gamma, const float* beta, const float* ada,
+                                      int ada_stride, float* coef, int B, int groups, int HW, float eps, float scale,
+                                      void* stream) {
     MAD_REQUIRE(partial1 && gamma && beta && coef, "mad_gn_finalize: null pointer");
     MAD_REQUIRE(C1 > 0 && nsplit1 > 0 && C2 >= 0 && (C2 == 0 || (partial2 && nsplit2 > 0)),
                 "mad_gn_finalize: bad partial-sum layout C1=%d nsplit1=%d C2=%d nsplit2=%d", C1, nsplit1, C2, nsplit2);
@@ -257,11 +266,11 @@ extern "C" int mad_gn_finalize(const float* partial1, int C1, int nsplit1, const
     if (longest >= 512)
         hipLaunchKernelGGL(gn_finalize_kernel<4>, dim3(groups, B), dim3(256), 0, (hipStream_t)stream, partial1, C1,
                            nsplit1, C2 ? partial2 : partial1, C2, C2 ? nsplit2 : 1, gamma, beta, ada, ada_stride, coef,
-                           groups, HW, eps);
+                           groups, HW, eps, scale);
     else
         hipLaunchKernelGGL(gn_finalize_kernel<1>, dim3(groups, B), dim3(64), 0, (hipStream_t)stream, partial1, C1,
                            nsplit1, C2 ? partial2 : partial1, C2, C2 ? nsplit2 : 1, gamma, beta, ada, ada_stride, coef,
-                           groups, HW, eps);
+                           groups, HW, eps, scale);
     return check_launch("mad_gn_finalize");
 }
 

@@ -31,6 +31,10 @@ from .unet_spec import GN_EPS, BlockSpec, UNetSpec, build_spec, gn_groups, spec_
 Tensor = torch.Tensor
 LOADER_NORM_MIN_RES = 16      # 3x3 convs above this resolution apply GroupNorm+SiLU in their loader
 IMG8_CONV = os.environ.get("MAD_IMG8", "1") != "0"   # 8x8 layers on the image-resident kernel (0: implicit GEMM)
+# the halo-tile kernel's weights stored tile by tile (0: (Cout,3,3,Cin) as every other kernel reads them), and its
+# loader transform in the prescaled form (0: coefficients and weights as they are)
+HALO_TILED = os.environ.get("MAD_HALO_TILED", "1") != "0"
+HALO_PRESCALE = os.environ.get("MAD_HALO_PRESCALE", "1") != "0"
 
 
 class _Params(nn.Module):
@@ -187,15 +191,38 @@ class DhariwalUNet(nn.Module):
             a.part = ops.gn_partial(a.t)
         return a.part
 
+    @staticmethod
+    def _halo_plan(b: BlockSpec):
+        """(the block's 3x3 convs run on the halo-tile kernel, conv0 / conv1 take norm+SiLU in their loader in the
+        prescaled form): fixed per block, so the packed weights can carry the matching factor."""
+        fused = ops.fused_conv_ok(b.res_out, b.res_out, b.out_channels)
+        in_loader = fused and b.res_out > LOADER_NORM_MIN_RES
+        return fused, HALO_PRESCALE and in_loader and not b.down, HALO_PRESCALE and in_loader
+
+    def _halo_w(self, e: dict, nm: str, pre: bool) -> Tensor:
+        """The halo-tile kernel's own copy of conv ``nm``'s weights, built from the fp32 parameter the first time
+        the block runs after a (re)pack: tile by tile in the order the kernel keeps them in LDS, times -ln(2) where
+        the conv's loader applies norm+SiLU in the prescaled form.  (A trainer that rewrites the pack in place drops
+        these entries instead of rewriting them.)"""
+        w = e.get(nm + ".wh")
+        if w is None:
+            w32 = self.get_parameter(f"{e['spec'].name}.{nm}.weight").detach().to(torch.float32).permute(0, 2, 3, 1)
+            sc = _lib.PRESCALE_W if pre else 1.0
+            dt = e[nm + ".w"].dtype
+            w = ops.halo_tile_weights(w32, dt, sc) if HALO_TILED else (w32 * sc).contiguous().to(dt)
+            e[nm + ".wh"] = w
+        return w
+
     def _block(self, e: dict, x: "_Act", skip: Optional["_Act"], ada: Tensor, ada_total: int) -> "_Act":
         b: BlockSpec = e["spec"]
         hw_in, hw_out = b.res_in * b.res_in, b.res_out * b.res_out
         xt, st = x.t, (None if skip is None else skip.t)
+        fused, pre0, pre1 = self._halo_plan(b)
         # norm0 over the (virtual) concatenation [x, skip]
         c0 = ops.gn_finalize(self._part(x), hw_in, e["norm0.g"], e["norm0.b"], gn_groups(b.in_channels), GN_EPS,
-                             partial2=None if skip is None else self._part(skip))
+                             partial2=None if skip is None else self._part(skip),
+                             scale=_lib.PRESCALE_COEF if pre0 else 1.0)
         ada_v = ada[:, e["ada_off"]:]
-        fused = ops.fused_conv_ok(b.res_out, b.res_out, b.out_channels)
         proj = None                          # 1x1 projection of the block input folded into conv1's launch
         if b.skip_conv and fused:
             res, mode, proj = None, _lib.RES_NONE, (xt, st, e["skip.w2d"])
@@ -215,24 +242,25 @@ class DhariwalUNet(nn.Module):
             in_loader = b.res_out > LOADER_NORM_MIN_RES
             if b.down:
                 h = ops.gn_apply(xt, c0, act=True, x2=st, pool=True)       # 2x2 mean after norm+SiLU
-                h, part = ops.conv3x3_fused(h, e["conv0.w"], e["conv0.b"], coef=None, want_stats=True)
+                h, part = ops.conv3x3_fused(h, self._halo_w(e, "conv0", pre0 and in_loader and not b.down), e["conv0.b"], coef=None, want_stats=True, w_tiled=HALO_TILED)
             elif in_loader:
-                h, part = ops.conv3x3_fused(xt, e["conv0.w"], e["conv0.b"], coef=c0, act=True, x2=st,
-                                            upsample=b.up, want_stats=True)
+                h, part = ops.conv3x3_fused(xt, self._halo_w(e, "conv0", pre0 and in_loader and not b.down), e["conv0.b"], coef=c0, act=True, x2=st,
+                                            upsample=b.up, want_stats=True, prescaled=pre0, w_tiled=HALO_TILED)
             else:
                 h = ops.gn_apply(xt, c0, act=True, x2=st)                  # before the nearest x2: same values
-                h, part = ops.conv3x3_fused(h, e["conv0.w"], e["conv0.b"], coef=None, upsample=b.up,
-                                            want_stats=True)
+                h, part = ops.conv3x3_fused(h, self._halo_w(e, "conv0", pre0 and in_loader and not b.down), e["conv0.b"], coef=None, upsample=b.up,
+                                            want_stats=True, w_tiled=HALO_TILED)
             c1 = ops.gn_finalize(part, hw_out, e["norm1.g"], e["norm1.b"], gn_groups(b.out_channels), GN_EPS,
-                                 ada=ada_v, ada_stride=ada_total)
+                                 ada=ada_v, ada_stride=ada_total, scale=_lib.PRESCALE_COEF if pre1 else 1.0)
             bias1 = e["conv1.b"] if proj is None else e["conv1+skip.b"]
             if in_loader:
-                y, part = ops.conv3x3_fused(h, e["conv1.w"], bias1, coef=c1, act=True, residual=res,
-                                            res_mode=mode, want_stats=True, skip=proj)
+                y, part = ops.conv3x3_fused(h, self._halo_w(e, "conv1", pre1 and in_loader), bias1, coef=c1, act=True, residual=res,
+                                            res_mode=mode, want_stats=True, skip=proj, prescaled=pre1,
+                                            w_tiled=HALO_TILED)
             else:
                 h = ops.gn_apply(h, c1, act=True)
-                y, part = ops.conv3x3_fused(h, e["conv1.w"], bias1, coef=None, residual=res,
-                                            res_mode=mode, want_stats=True, skip=proj)
+                y, part = ops.conv3x3_fused(h, self._halo_w(e, "conv1", pre1 and in_loader), bias1, coef=None, residual=res,
+                                            res_mode=mode, want_stats=True, skip=proj, w_tiled=HALO_TILED)
             out = _Act(y, part)
         elif IMG8_CONV and ops.img8_conv_pays(xt.shape[0], b.out_channels) and ops.img8_conv_ok(b.res_out, b.res_out, b.in_channels if b.down else xt.shape[3],
                                             0 if (b.down or st is None) else st.shape[3], b.out_channels, xt.dtype):

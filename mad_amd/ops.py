@@ -286,20 +286,49 @@ def conv2d(x1: Tensor, w: Tensor, bias: Optional[Tensor], x2: Optional[Tensor] =
     return (y, stats) if want_stats else y
 
 
+def halo_tile_weights(w: Tensor, dtype: torch.dtype, scale: float = 1.0) -> Tensor:
+    """(Cout, 3, 3, Cin) weights -> the tiled layout of ``mad_conv3x3_fused`` (MAD_W_TILED), in ``dtype``, multiplied
+    by ``scale`` first (``_lib.PRESCALE_W`` for the prescaled form).  Result (Cout/16, Cin/CK, 9, 16, 4, VEC): one KiB
+    per (16-row block, 64-byte channel chunk, tap), rows of four 16-byte pieces in the order the kernel keeps them in
+    LDS (piece p of row r holds logical piece p ^ (-(r >> 2) & 3))."""
+    Cout, kh, kw, Cin = w.shape
+    vec = 16 // torch.empty((), dtype=dtype).element_size()
+    ck = 4 * vec
+    if (kh, kw) != (3, 3) or Cout % 16 or Cin % ck:
+        raise ValueError(f"halo_tile_weights: shape {tuple(w.shape)} does not tile (Cout % 16, Cin % {ck})")
+    wq = (w.float() * scale).to(dtype) if scale != 1.0 else w.to(dtype)
+    w6 = wq.reshape(Cout // 16, 16, 9, Cin // ck, 4, vec).permute(0, 3, 2, 1, 4, 5)     # (blk, chunk, tap, row, piece, v)
+    src = torch.tensor([[p ^ ((-(r >> 2)) & 3) for p in range(4)] for r in range(16)], device=w.device)
+    idx = src.view(1, 1, 1, 16, 4, 1).expand(Cout // 16, Cin // ck, 9, 16, 4, vec)
+    return torch.gather(w6, 4, idx).contiguous()
+
+
 def conv3x3_fused(x1: Tensor, w: Tensor, bias: Optional[Tensor], coef: Optional[Tensor] = None, act: bool = True,
                   x2: Optional[Tensor] = None, residual: Optional[Tensor] = None, res_mode: int = _lib.RES_NONE,
-                  upsample: bool = False, want_stats: bool = False, skip: Optional[tuple] = None):
+                  upsample: bool = False, want_stats: bool = False, skip: Optional[tuple] = None,
+                  prescaled: bool = False, w_tiled: bool = False):
     """Halo-tile 3x3 conv with the input's GroupNorm(+SiLU) applied in the loader (coef (B,C,2) or None)
     and, optionally, per-tile statistics of the output (B, tiles, Cout, 2) for the next GroupNorm.
     ``skip=(s1, s2_or_None, sw)`` adds the 1x1 projection ``sw (Cout, SC1+SC2)`` of the raw concatenation
-    [s1, s2] in the same launch (``bias`` must then already hold the sum of both layers' biases)."""
+    [s1, s2] in the same launch (``bias`` must then already hold the sum of both layers' biases).
+    ``prescaled``: coef comes from ``gn_finalize(..., scale=_lib.PRESCALE_COEF)`` and w carries ``_lib.PRESCALE_W``;
+    ``w_tiled``: w is the result of ``halo_tile_weights``."""
     _dev(x1, x2, w, bias, coef, residual)
     B, Hs, Ws, C1 = x1.shape
     C2 = 0 if x2 is None else x2.shape[3]
     H, W_ = (2 * Hs, 2 * Ws) if upsample else (Hs, Ws)
-    Cout = w.shape[0]
-    if w.dtype != x1.dtype or tuple(w.shape) != (Cout, 3, 3, C1 + C2):
-        raise ValueError(f"conv3x3_fused weight {tuple(w.shape)}/{w.dtype} does not match input {C1}+{C2}/{x1.dtype}")
+    if w_tiled:
+        vec = 16 // x1.element_size()
+        Cout = w.shape[0] * 16
+        if w.dtype != x1.dtype or tuple(w.shape) != (Cout // 16, (C1 + C2) // (4 * vec), 9, 16, 4, vec) or not w.is_contiguous():
+            raise ValueError(f"conv3x3_fused tiled weight {tuple(w.shape)}/{w.dtype} does not match input {C1}+{C2}/{x1.dtype}")
+    else:
+        Cout = w.shape[0]
+        if w.dtype != x1.dtype or tuple(w.shape) != (Cout, 3, 3, C1 + C2):
+            raise ValueError(f"conv3x3_fused weight {tuple(w.shape)}/{w.dtype} does not match input {C1}+{C2}/{x1.dtype}")
+    if prescaled and (coef is None or not act):
+        raise ValueError("conv3x3_fused: the prescaled form needs coef and the activation")
+    mode = (_lib.ACT_SILU if act else 0) | (_lib.ACT_PRESCALED if prescaled else 0) | (_lib.W_TILED if w_tiled else 0)
     if coef is not None and (coef.dtype != torch.float32 or tuple(coef.shape) != (B, C1 + C2, 2)):
         raise ValueError("conv3x3_fused coef must be fp32 (B, C, 2)")
     if residual is not None:
@@ -321,14 +350,14 @@ def conv3x3_fused(x1: Tensor, w: Tensor, bias: Optional[Tensor], coef: Optional[
                 or tuple(sw.shape) != (Cout, SC1 + SC2) or sw.dtype != x1.dtype or s1.dtype != x1.dtype):
             raise ValueError("conv3x3_fused: projected input / weight shapes do not fit the output")
         end = TIMER.bracket("conv3x3_halo", 2.0 * B * H * W_ * Cout * ((C1 + C2) * 9 + SC1 + SC2))
-        check(lib.mad_conv3x3_fused_skip(_ptr(x1), C1, _ptr(x2), C2, _ptr(coef), int(act), _ptr(w), _ptr(bias),
+        check(lib.mad_conv3x3_fused_skip(_ptr(x1), C1, _ptr(x2), C2, _ptr(coef), mode, _ptr(w), _ptr(bias),
                                          _ptr(s1), SC1, _ptr(s2), SC2, _ptr(sw), _ptr(y), _ptr(stats),
                                          _dtype_code(x1), B, H, W_, Cout, _stream()), "mad_conv3x3_fused_skip")
         if end is not None:
             end.record()
         return (y, stats) if want_stats else y
     end = TIMER.bracket("conv3x3_halo", 2.0 * B * H * W_ * Cout * (C1 + C2) * 9)
-    check(lib.mad_conv3x3_fused(_ptr(x1), C1, _ptr(x2), C2, _ptr(coef), int(act), _ptr(w), _ptr(bias), _ptr(residual),
+    check(lib.mad_conv3x3_fused(_ptr(x1), C1, _ptr(x2), C2, _ptr(coef), mode, _ptr(w), _ptr(bias), _ptr(residual),
                                 res_mode, _ptr(y), _ptr(stats), _dtype_code(x1), B, H, W_, Cout, int(upsample),
                                 _stream()), "mad_conv3x3_fused")
     if end is not None:
@@ -637,9 +666,10 @@ def gn_partial(x1: Tensor, x2: Optional[Tensor] = None) -> Tensor:
 
 
 def gn_finalize(partial: Tensor, HW: int, gamma: Tensor, beta: Tensor, groups: int, eps: float,
-                ada: Optional[Tensor] = None, ada_stride: int = 0, partial2: Optional[Tensor] = None) -> Tensor:
+                ada: Optional[Tensor] = None, ada_stride: int = 0, partial2: Optional[Tensor] = None,
+                scale: float = 1.0) -> Tensor:
     """Partial sums (B, nsplit, C, 2) over HW pixels (optionally a second slab for concatenated
-    channels) -> coef (B, C, 2) with y = x*a + d."""
+    channels) -> coef (B, C, 2) with y = x*a + d, every pair multiplied by ``scale``."""
     _dev(partial, partial2, gamma, beta)
     B, ns1, C1, _ = partial.shape
     ns2, C2 = (0, 0) if partial2 is None else (partial2.shape[1], partial2.shape[2])
@@ -647,9 +677,9 @@ def gn_finalize(partial: Tensor, HW: int, gamma: Tensor, beta: Tensor, groups: i
     if gamma.numel() != C or beta.numel() != C:
         raise ValueError("GroupNorm gain/offset length does not match the channel count")
     coef = torch.empty((B, C, 2), dtype=torch.float32, device=partial.device)
-    check(lib.mad_gn_finalize(_ptr(partial), C1, ns1, _ptr(partial2), C2, ns2, _ptr(gamma), _ptr(beta),
-                              None if ada is None else ada.data_ptr(), ada_stride, _ptr(coef), B, groups, HW,
-                              float(eps), _stream()), "mad_gn_finalize")
+    check(lib.mad_gn_finalize_scaled(_ptr(partial), C1, ns1, _ptr(partial2), C2, ns2, _ptr(gamma), _ptr(beta),
+                                     None if ada is None else ada.data_ptr(), ada_stride, _ptr(coef), B, groups, HW,
+                                     float(eps), float(scale), _stream()), "mad_gn_finalize")
     return coef
 
 

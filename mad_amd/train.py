@@ -183,6 +183,8 @@ class UNetTrainer:
         for e in P["blocks"]:
             b = e["spec"]
             n = b.name
+            e.pop("conv0.wh", None)          # the inference path's own weight copies: rebuilt when it next runs
+            e.pop("conv1.wh", None)
             if b.skip_conv:
                 torch.add(e["conv1.b"], e["skip.b"], out=e["conv1+skip.b"])
             if b.attention:

@@ -337,10 +337,13 @@ FUSED_CASES = [
 @pytest.mark.parametrize("case", FUSED_CASES)
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("bn", ["128", "64", "192", "128w", "192w"])
-def test_conv3x3_fused(dev, case, dt, bn, monkeypatch):
+@pytest.mark.parametrize("fmt", ["plain", "tiled", "tiled+pre"])
+def test_conv3x3_fused(dev, case, dt, bn, fmt, monkeypatch):
     """Both workgroup widths (128 and 64 output channels) of the halo-tile kernel, ("192") the split of an
     odd multiple of 64 channels over a wide and a narrow launch, and ("w") the 16x32-pixel eight-wave tiles
-    forced wherever they fit (bf16, width a multiple of 32, 128-channel workgroups)."""
+    forced wherever they fit (bf16, width a multiple of 32, 128-channel workgroups).  fmt: the weights as
+    (Cout,3,3,Cin), tile by tile, and tile by tile with the loader transform in its prescaled form (coefficients
+    times -log2(e), weights times -ln(2)): the same convolution every time."""
     from mad_amd import _lib, ops
     wide = bn.endswith("w")
     bn = bn.rstrip("w")
@@ -376,11 +379,14 @@ def test_conv3x3_fused(dev, case, dt, bn, monkeypatch):
     elif res == "down":
         want = want + F.avg_pool2d(q(r).double(), 2)
     mode = {"none": _lib.RES_NONE, "same": _lib.RES_SAME, "up": _lib.RES_UP, "down": _lib.RES_DOWN}[res]
-    out = ops.conv3x3_fused(_nhwc(x1, dt, dev), w.permute(0, 2, 3, 1).contiguous().to(dt).to(dev), bias.to(dev),
-                            coef=None if coef is None else coef.contiguous().to(dev), act=True,
+    pre = fmt == "tiled+pre" and fuse
+    wk = w.permute(0, 2, 3, 1).contiguous().to(dev)
+    wk = ops.halo_tile_weights(wk, dt, _lib.PRESCALE_W if pre else 1.0) if fmt != "plain" else wk.to(dt)
+    ck = None if coef is None else (coef * _lib.PRESCALE_COEF if pre else coef).contiguous().to(dev)
+    out = ops.conv3x3_fused(_nhwc(x1, dt, dev), wk, bias.to(dev), coef=ck, act=True,
                             x2=None if x2 is None else _nhwc(x2, dt, dev),
                             residual=None if r is None else _nhwc(r, dt, dev), res_mode=mode, upsample=up,
-                            want_stats=want_stats)
+                            want_stats=want_stats, prescaled=pre, w_tiled=fmt != "plain")
     y, stats = out if want_stats else (out, None)
     tol = 3e-5 if dt == torch.float32 else 8e-3
     assert rel_err(_nchw(y), want) < tol
@@ -402,14 +408,19 @@ def test_conv3x3_fused(dev, case, dt, bn, monkeypatch):
         c1 = ops.gn_finalize(stats, H * H, gamma.to(dev), beta.to(dev), 32, 1e-5)
         c2 = ops.gn_coef(y, gamma.to(dev), beta.to(dev), 32, 1e-5)
         assert rel_err(c1.cpu(), c2.cpu()) < 1e-4
+        # the scaled form writes the same pairs times the factor
+        c3 = ops.gn_finalize(stats, H * H, gamma.to(dev), beta.to(dev), 32, 1e-5, scale=_lib.PRESCALE_COEF)
+        assert torch.equal(c3, c1 * torch.tensor(_lib.PRESCALE_COEF, dtype=torch.float32))
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("bn", ["128", "64", "128w"])
 @pytest.mark.parametrize("case", [(2, 32, 64, 64, 32, 128), (1, 16, 128, 96, 0, 192), (1, 64, 64, 32, 64, 256)])
-def test_conv3x3_fused_projection(dev, case, dt, bn, monkeypatch):
-    """conv1 + the residual branch's 1x1 projection of the (two-source) block input in one launch."""
-    from mad_amd import ops
+@pytest.mark.parametrize("fmt", ["plain", "tiled+pre"])
+def test_conv3x3_fused_projection(dev, case, dt, bn, fmt, monkeypatch):
+    """conv1 + the residual branch's 1x1 projection of the (two-source) block input in one launch (fmt as in
+    test_conv3x3_fused; the projection's weights are never scaled)."""
+    from mad_amd import _lib, ops
     monkeypatch.setenv("MAD_HALO_WIDE", "2" if bn.endswith("w") else "0")
     bn = bn.rstrip("w")
     monkeypatch.setenv("MAD_HALO_BN", bn)
@@ -426,10 +437,13 @@ def test_conv3x3_fused_projection(dev, case, dt, bn, monkeypatch):
         hin = q(hin)                                           # the loader rounds the activated value
     sin = q(s1) if s2 is None else torch.cat([q(s1), q(s2)], 1)
     want = F.conv2d(hin.double(), q(w).double(), bias.double(), padding=1) + F.conv2d(sin.double(), q(sw).double())
-    y, stats = ops.conv3x3_fused(_nhwc(h, dt, dev), w.permute(0, 2, 3, 1).contiguous().to(dt).to(dev), bias.to(dev),
-                                 coef=coef.to(dev), act=True, want_stats=True,
+    pre = fmt == "tiled+pre"
+    wk = w.permute(0, 2, 3, 1).contiguous().to(dev)
+    wk = ops.halo_tile_weights(wk, dt, _lib.PRESCALE_W) if pre else wk.to(dt)
+    y, stats = ops.conv3x3_fused(_nhwc(h, dt, dev), wk, bias.to(dev),
+                                 coef=(coef * _lib.PRESCALE_COEF if pre else coef).to(dev), act=True, want_stats=True,
                                  skip=(_nhwc(s1, dt, dev), None if s2 is None else _nhwc(s2, dt, dev),
-                                       sw.reshape(Cout, -1).to(dt).to(dev)))
+                                       sw.reshape(Cout, -1).to(dt).to(dev)), prescaled=pre, w_tiled=pre)
     assert rel_err(_nchw(y), want) < (2e-5 if dt == torch.float32 else 8e-3)
     yf = y.float()
     got = stats.sum(1).cpu()

@@ -7,7 +7,7 @@ import numpy as np, torch
 from mad_amd import ops, _lib
 
 dev = torch.device("cuda:0")
-B, H, Cin, Cout = 32, int(sys.argv[1]) if len(sys.argv) > 1 else 256, 128, 128
+B, H, Cin, Cout = int(sys.argv[3]) if len(sys.argv) > 3 else 32, int(sys.argv[1]) if len(sys.argv) > 1 else 256, int(sys.argv[4]) if len(sys.argv) > 4 else 128, 128
 fuse = (sys.argv[2] if len(sys.argv) > 2 else "1") == "1"
 x = (torch.randn(B, H, H, Cin, device=dev) * 0.7).to(torch.bfloat16)
 w = (torch.randn(Cout, 3, 3, Cin, device=dev) / math.sqrt(9 * Cin)).to(torch.bfloat16)
