@@ -185,8 +185,6 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / (TW / 16) / 2) void conv3x3
 
     const int Ctot = a.C1 + a.C2;
     const int nchunks = Ctot / CK;
-    // tiles away from the image border have no padding in their halo: their transform skips the zeroing selects
-    const bool tile_pad = ty0 == 0 || tx0 == 0 || ty0 + HT >= a.H || tx0 + TW >= a.W;
 #ifdef MAD_HALO_STAMPS
     unsigned* const stamp_lds = reinterpret_cast<unsigned*>(smem + halo_lds_bytes<BN, TW>() - 4096);
     const bool stamp_on = blockIdx.x == gridDim.x / 2 + 3;
@@ -320,8 +318,12 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / (TW / 16) / 2) void conv3x3
     // the first coefficient pair are requested at the top of the tap; each later coefficient pair one pair ahead.
     constexpr int XSTRIDE = 16 / XPAIRS;
     uint4 xraw; float4 xcf[1]; float xt[2], xu[2]; unsigned xout[4];
+    // the "1" of the sigmoid's denominator 1 + 2^u: +infinity for an item that is padding, whose reciprocal is 0
+    // and whose product with the (finite) t is the zero the convolution pads with -- no selects on the way out
+    float xone = 1.0f;
     const unsigned char* xaddr = nullptr; const float* xcoef = nullptr;
     auto xf_begin = [&](int j, int buf) {
+        xone = __uint_as_float(0x3f800000u + (((padmask >> j) & 1u) << 30));     // 1.0f, or 0x7f800000 = +inf
         const int item = tid + NT * j;
         xaddr = halo0 + buf * HALO_BUF + item * 16;
         xraw = *reinterpret_cast<const uint4*>(xaddr);
@@ -350,7 +352,7 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / (TW / 16) / 2) void conv3x3
         } else if (k == 1) {
             // the next pair's coefficients are requested into the registers the multiply-adds have just read
             if (pr + 1 < XPAIRS) xcf[0] = *reinterpret_cast<const float4*>(xcoef + 4 * (pr + 1));
-            xu[0] = 1.0f + __builtin_amdgcn_exp2f(PRE ? xt[0] : xu[0]); xu[1] = 1.0f + __builtin_amdgcn_exp2f(PRE ? xt[1] : xu[1]);
+            xu[0] = xone + __builtin_amdgcn_exp2f(PRE ? xt[0] : xu[0]); xu[1] = xone + __builtin_amdgcn_exp2f(PRE ? xt[1] : xu[1]);
         } else if (k == 2) {
             div2(xt[0], xt[1], xu[0], xu[1]);
         } else {
@@ -361,8 +363,7 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / (TW / 16) / 2) void conv3x3
                 xout[pr] = __builtin_bit_cast(unsigned, __builtin_convertvector(v2, bf16x2_t));
             } else { xout[2 * pr] = __float_as_uint(xt[0]); xout[2 * pr + 1] = __float_as_uint(xt[1]); }
             if (pr == XPAIRS - 1) {
-                uint4 o = make_uint4(xout[0], xout[1], xout[2], xout[3]);
-                if (tile_pad && ((padmask >> j) & 1)) o = make_uint4(0u, 0u, 0u, 0u);
+                const uint4 o = make_uint4(xout[0], xout[1], xout[2], xout[3]);     // zeros already where padding
                 const int item = tid + NT * j;
                 if (j < HALO_ROUNDS - 1 || item < HALO_ITEMS)
                     *reinterpret_cast<uint4*>(const_cast<unsigned char*>(xaddr)) = o;
