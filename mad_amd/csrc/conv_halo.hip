@@ -185,6 +185,21 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / (TW / 16) / 2) void conv3x3
 
     const int Ctot = a.C1 + a.C2;
     const int nchunks = Ctot / CK;
+    // The accumulators start from the bias of their channels (the epilogue then has nothing to add); the NCHW form
+    // adds it when it writes.  Register e of a lane: M16 channel 16*j + 4*fh + e; 32x32: 32*j + 8*(e/4) + 4*fh + e%4.
+    // Requested here, ahead of the tile geometry, and pinned before the first copy is issued: an ordinary load
+    // waited for after the copies would make the compiler's wait cover the copies as well.
+    constexpr int NB4 = M16 ? 2 * TN : 4 * TN;
+    f32x4 bias4[NB4];
+    {
+        const bool bias_init = !OUT_NCHW && a.bias != nullptr;
+        const int fh_ = M16 ? lane >> 4 : lane >> 5;
+#pragma unroll
+        for (int k = 0; k < NB4; ++k) {
+            bias4[k] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            if (bias_init) bias4[k] = *reinterpret_cast<const f32x4*>(a.bias + n0 + wn * (TN * 32) + k * (M16 ? 16 : 8) + 4 * fh_);
+        }
+    }
 #ifdef MAD_HALO_STAMPS
     unsigned* const stamp_lds = reinterpret_cast<unsigned*>(smem + halo_lds_bytes<BN, TW>() - 4096);
     const bool stamp_on = blockIdx.x == gridDim.x / 2 + 3;
@@ -218,7 +233,8 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / (TW / 16) / 2) void conv3x3
         const int p = item >> 2;
         const int hy = p / HSX, hx = p - hy * HSX;
         const int iy = ty0 - 1 + hy, ix = tx0 - 1 + hx;
-        const bool ok = item < HALO_ITEMS && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+        // (unsigned compares and bitwise ands: one mask per item, no branches)
+        const bool ok = (item < HALO_ITEMS) & ((unsigned)iy < (unsigned)a.H) & ((unsigned)ix < (unsigned)a.W);
         const int sy = a.upsample ? iy >> 1 : iy, sx = a.upsample ? ix >> 1 : ix;
         if constexpr (FUSE) rel16[j / 2] |= (unsigned)(ok ? (sy - sy0) * a.Ws + (sx - sx0) : 0) << (16 * (j & 1));
         else src_pix[j] = ok ? (b * a.Hs + sy) * a.Ws + sx : -1;
@@ -436,6 +452,19 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / (TW / 16) / 2) void conv3x3
         }
     };
 
+    // ---- prologue: the whole halo of chunk 0, its coefficients, weight tiles 0 and 1
+#pragma unroll
+    for (int k = 0; k < NB4; ++k) asm volatile("" : "+v"(bias4[k]));
+    MAD_STAMP_PHASE(11)
+    if (FUSE) dma_coef(0, 0);
+#pragma unroll
+    for (int j = 0; j < HALO_ROUNDS; ++j) dma_item(0, j, 0);
+#pragma unroll
+    for (int t = 0; t < PF; ++t) stage_w(0, t, t);
+    // (the copies are in flight: what follows -- fragment addresses, the accumulators' start values -- runs under
+    // their latency instead of in front of it)
+    __builtin_amdgcn_sched_barrier(0);
+
     // ---- fragment addressing.  32x32x16 form: lane&31 = row of a 32-row fragment, lane>>5 = which of two adjacent
     // 16-byte chunks.  16x16x32 form (M16): lane&15 = row of a 16-row fragment (one tile row of pixels / 16
     // channels), lane>>4 = chunk of the 64-byte row.
@@ -459,44 +488,33 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / (TW / 16) / 2) void conv3x3
 
     f32x16 acc[M16 ? 1 : TM][M16 ? 1 : TN];
     f32x4 acc16[M16 ? TM16 : 1][M16 ? TN16 : 1];
-    // The accumulators start from the bias of their channels (the epilogue then has nothing to add); the NCHW form
-    // adds it when it writes.  Register e of a lane: M16 channel 16*j + 4*fh + e; 32x32: 32*j + 8*(e/4) + 4*fh + e%4.
-    const bool bias_init = !OUT_NCHW && a.bias != nullptr;
     if constexpr (M16) {
+        static_assert(NB4 == TN16, "one bias quad per 16-channel fragment");
 #pragma unroll
-        for (int j = 0; j < TN16; ++j) {
-            f32x4 b4 = {0.0f, 0.0f, 0.0f, 0.0f};
-            if (bias_init) b4 = *reinterpret_cast<const f32x4*>(a.bias + n0 + wn * (TN * 32) + j * 16 + 4 * fh);
+        for (int j = 0; j < TN16; ++j)
 #pragma unroll
-            for (int i = 0; i < TM16; ++i) acc16[i][j] = b4;
-        }
+            for (int i = 0; i < TM16; ++i) acc16[i][j] = bias4[j];
     } else {
+        static_assert(NB4 == 4 * TN, "four bias quads per 32-channel fragment");
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                f32x4 b4 = {0.0f, 0.0f, 0.0f, 0.0f};
-                if (bias_init) b4 = *reinterpret_cast<const f32x4*>(a.bias + n0 + wn * (TN * 32) + j * 32 + 8 * g4 + 4 * fh);
+            for (int g4 = 0; g4 < 4; ++g4)
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) acc[i][j][4 * g4 + e] = b4[e];
-            }
+                    for (int e = 0; e < 4; ++e) acc[i][j][4 * g4 + e] = bias4[4 * j + g4][e];
     }
 
-    // ---- prologue: the whole halo of chunk 0, its coefficients, weight tiles 0 and 1
-    if (FUSE) dma_coef(0, 0);
-#pragma unroll
-    for (int j = 0; j < HALO_ROUNDS; ++j) dma_item(0, j, 0);
-#pragma unroll
-    for (int t = 0; t < PF; ++t) stage_w(0, t, t);
     if (FUSE) {
         // One wait for the table and the whole halo (the weight tiles, issued last, may still be in flight), then
         // every item is read before any is rewritten and the coefficient rows of item j+1 are requested before
         // item j is computed: the items' dependent chains (LDS read, multiply-add, exp, reciprocal, product,
         // pack, LDS write) overlap instead of running one behind the other.
         static_assert(PF * NW < 64, "vmcnt range");
+        MAD_STAMP_PHASE(12)
         dma_wait_upto<PF * NW>();
+        MAD_STAMP_PHASE(13)
         constexpr int FULL = MINI ? HALO_ROUNDS - 1 : HALO_ROUNDS;
         uint4 raw[FULL];
 #pragma unroll
@@ -528,6 +546,7 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / (TW / 16) / 2) void conv3x3
         }
         if (MINI) xform_mini(0);
     }
+    MAD_STAMP_PHASE(14)
     dma_wait_all();
 
     // Operations a wave issues at tap t, in order: the coefficient copy (t == 0, FUSE), one halo item (t < 6),
@@ -571,18 +590,25 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / (TW / 16) / 2) void conv3x3
                 default: dma_wait_upto<8>(); break;
             }
             MAD_STAMP(1)
+#ifndef MAD_KO_BAR
             __syncthreads();
+#endif
             MAD_STAMP(2)
             // buffer of K-tile k = 9*cc + tap is k % NWBUF: a compile-time value when NWBUF divides 9
             auto wbuf = [&](int c_, int t_) { return 9 % NWBUF == 0 ? t_ % NWBUF : (c_ * (9 % NWBUF) + t_) % NWBUF; };
             const unsigned char* wt = wt0 + wbuf(cc, tap) * WTILE_BYTES;
             // item tap-3 of the next chunk was issued three taps ago, before weight tile `tap`: it has landed,
             // and is transformed in place in 16 pieces behind this tap's 16 MFMAs
+#ifdef MAD_KO_XF
+            const bool do_x = false;
+#else
             const bool do_x = FUSE && !LAST && tap >= 3 && tap - 3 < HALO_ROUNDS;
+#endif
             const bool mini_tap = MINI && do_x && tap - 3 == HALO_ROUNDS - 1;
             // what rides behind MFMA number sidx of the tap's NMM: the requests for later taps and (unless the
             // transform runs as one block) the transform pieces
             auto behind_mma = [&](int sidx, int NMM) {
+#ifndef MAD_KO_DMA
                 if (!LAST && sidx == MAD_DMA_HALO_SIDX * NMM / 16) {
                     if (FUSE && tap == 0) dma_coef(ccn, nb);
                     if (tap < HALO_ROUNDS) dma_item(ccn, tap, nb);
@@ -591,6 +617,7 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / (TW / 16) / 2) void conv3x3
                     if (tap + PF < 9) stage_w(cc, tap + PF, wbuf(cc, tap + PF));
                     else if (!LAST) stage_w(ccn, tap + PF - 9, wbuf(cc + 1, tap + PF - 9));
                 }
+#endif
                 if (do_x && !MAD_XF_PHASED) {
 #pragma unroll
                     for (int xs = sidx * 16 / NMM; xs < (sidx + 1) * 16 / NMM; ++xs) {
@@ -615,6 +642,17 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / (TW / 16) / 2) void conv3x3
                 constexpr int NG = TM16 / 2;           // groups of 2*TN16 MFMAs: a pair of pixel rows x all channels
                 constexpr int NMM = TM16 * TN16;
                 uint4 afs[2][2], bfs[TN16];
+#ifdef MAD_KO_LDS
+                auto opaque = [](uint4& v) { asm volatile("" : "=v"(v.x), "=v"(v.y), "=v"(v.z), "=v"(v.w)); };
+                auto read_group = [&](int g) {
+                    if (g == 0) {
+#pragma unroll
+                        for (int q = 0; q < TN16; ++q) opaque(bfs[q]);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) opaque(afs[g & 1][q]);
+                };
+#else
                 auto read_group = [&](int g) {
                     if (g == 0) {
 #pragma unroll
@@ -624,6 +662,7 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / (TW / 16) / 2) void conv3x3
                     for (int q = 0; q < 2; ++q)
                         afs[g & 1][q] = *reinterpret_cast<const uint4*>(halo + a_off[kx][0] + (2 * g + q + ky) * HSX * HROW);
                 };
+#endif
                 read_group(0);
                 if (do_x && !MAD_XF_PHASED) { if (mini_tap) xm_begin(nb); else xf_begin(tap - 3, nb); }
 #pragma unroll

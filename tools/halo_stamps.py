@@ -36,3 +36,9 @@ names = ["prologue", "main loop", "(wait residual+sync)", "h0 acc->LDS+sync", "h
 for wv in range(4):
     d = [(ph[wv, i + 1] - ph[wv, i]) & 0xffffffff for i in range(10)]
     print(f"wave {wv}: " + "  ".join(f"{n} {v}" for n, v in zip(names, d)))
+pro = full[:4, 2:6, 6]      # prologue stamps 11..14: geometry done, copies issued, halo landed, transform done
+t0 = full[:4, 0, 5]
+t1 = full[:4, 1, 5]
+for wv in range(4):
+    d = [(pro[wv, 0] - t0[wv]) & 0xffffffff] + [(pro[wv, i + 1] - pro[wv, i]) & 0xffffffff for i in range(3)] + [(t1[wv] - pro[wv, 3]) & 0xffffffff]
+    print(f"wave {wv} prologue: geometry {d[0]}  issue copies {d[1]}  wait halo {d[2]}  transform {d[3]}  wait weights {d[4]}")
