@@ -191,8 +191,12 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(const T* __restrict_
 // The same algorithm arranged for the vector-issue budget of the bf16 case, where the softmax (not the
 // matrix pipe) sets the pace at head_dim 64: per score element one multiply-add, one exp2, one add and
 // half a conversion are all that is left in the tile loop.
-//   * 64-key tiles, two K/V buffers in LDS, ONE barrier per tile: tile t+1 is fetched into registers
-//     before the products of tile t and written to the other buffer after them.
+//   * 64-key tiles, three K/V buffers in LDS filled by LDS-DMA two tiles ahead (no staging registers, no LDS
+//     stores from the waves), counted waits, ONE barrier per tile.  A copy instruction writes 64 x 16 bytes
+//     lane-linearly, i.e. 8 whole 128-byte rows, so the bank-conflict-free layouts are produced on the SOURCE side:
+//     the lane that fills physical 16-byte piece p of row r fetches logical piece p ^ ((r>>1)&7) of a K row
+//     (every ds_read_b128 of a fragment conflict-free) and p ^ 4*((r>>1)&1) of a V row (the 64-byte halves of
+//     row pairs swapped: the four rows a 32-lane group of ds_read_b64_tr_b16 touches fall on distinct banks).
 //   * exp2 domain: p = exp2(s*log2(e) - m2), the scale and the running maximum folded into one fma.
 //   * The running maximum moves only when a tile's maximum exceeds it by more than RESCALE_THR (a
 //     wave-uniform decision): p is then bounded by 2^RESCALE_THR instead of 1, which fp32 sums and the
@@ -211,17 +215,27 @@ __device__ __forceinline__ float max3f(float a, float b, float c) { return __bui
 template <int NW>
 __global__ __launch_bounds__(NW * 64) void attention_bf16_kernel(const bf16_t* __restrict__ qkv,
                                                                   bf16_t* __restrict__ out,
-                                                                  float* __restrict__ lse, int L, int heads) {
-    constexpr int ROW = 128, VROW = 192, CHUNKS = 8, VEC = 8;
-    constexpr int NT = NW * 64;
-    constexpr int K_BYTES = KT2 * ROW, V_BYTES = KT2 * VROW;
-    __shared__ __attribute__((aligned(16))) unsigned char k_lds[2 * K_BYTES];
-    __shared__ __attribute__((aligned(16))) unsigned char v_lds[2 * V_BYTES];
+                                                                  float* __restrict__ lse, int L, int heads, int B) {
+    constexpr int ROW = 128, VEC = 8;
+    constexpr int K_BYTES = KT2 * ROW, TILE_BYTES = 2 * K_BYTES, NBUF = 3;     // a buffer: the K rows, then the V rows
+    __shared__ __attribute__((aligned(1024))) unsigned char kv_lds[NBUF * TILE_BYTES];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.z, head = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // Workgroups are handed to the eight XCDs round-robin by their linear index, and every query block of a
+    // (sample, head) reads that pair's whole K and V: the one-dimensional grid is mapped so that all query blocks of
+    // a pair run on ONE XCD, whose L2 then holds its K and V once (with the pair as the slow grid dimension eight
+    // XCDs each fetched them from memory, and the kernel ran at the speed of that traffic).
+    const int nq = L / (NW * 32), nbh = heads * B;
+    int bh, qb;
+    if ((nbh & 7) == 0) {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        bh = (slot / nq) * 8 + xcd; qb = slot % nq;
+    } else {
+        bh = blockIdx.x / nq; qb = blockIdx.x % nq;
+    }
+    const int b = bh / heads, head = bh % heads;
     const int C3 = heads * 3 * HD;
-    const int q0 = (blockIdx.x * NW + wave) * 32;
+    const int q0 = (qb * NW + wave) * 32;
     const int qi = lane & 31, fh = lane >> 5;
     const bf16_t* base = qkv + (size_t)b * L * C3 + head * 3 * HD;
 
@@ -241,6 +255,7 @@ __global__ __launch_bounds__(NW * 64) void attention_bf16_kernel(const bf16_t* _
             qf[kk] = v.raw;
         }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the Q loads: the counted waits below see only the copies
 
     f32x16 o[2];
 #pragma unroll
@@ -248,40 +263,52 @@ __global__ __launch_bounds__(NW * 64) void attention_bf16_kernel(const bf16_t* _
     float m2 = -1.0e30f, l_run = 0.0f;          // running maximum in exp2 units, running sum
     constexpr float LOG2E = 1.44269504088896340736f;
 
-    // a tile is 64 keys x (8 K chunks + 8 V chunks) of 16 bytes
-    constexpr int PER_THREAD = KT2 * CHUNKS / NT;
-    static_assert(KT2 * CHUNKS % NT == 0, "whole chunks per thread");
-    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    u32x4 kreg[PER_THREAD], vreg[PER_THREAD];
-    auto fetch = [&](int k0) {
+    // A tile is 64 keys x (128 bytes of K + 128 bytes of V) = 16 copy instructions of 8 rows each, PER_WAVE per wave:
+    // instruction i of the K (V) half covers rows 8i .. 8i+7.  Per-lane source offsets from the tile's first key:
+    constexpr int PER_HALF = 8 / NW, PER_WAVE = 2 * PER_HALF;
+    static_assert(8 % NW == 0, "whole copy instructions per wave");
+    unsigned koff[PER_HALF], voff[PER_HALF];
 #pragma unroll
-        for (int i = 0; i < PER_THREAD; ++i) {
-            const int c = tid + i * NT;
-            const int r = c / CHUNKS, ch = c % CHUNKS;
-            const bf16_t* krow = base + (size_t)(k0 + r) * C3 + HD;
-            kreg[i] = *reinterpret_cast<const u32x4*>(krow + ch * VEC);
-            vreg[i] = *reinterpret_cast<const u32x4*>(krow + HD + ch * VEC);
+    for (int j = 0; j < PER_HALF; ++j) {
+        const int r = 8 * (wave + NW * j) + (lane >> 3), pc = lane & 7;
+        koff[j] = (unsigned)((r * C3 + HD + (pc ^ ((r >> 1) & 7)) * VEC) * 2);
+        voff[j] = (unsigned)((r * C3 + 2 * HD + (pc ^ (((r >> 1) & 1) << 2)) * VEC) * 2);
+    }
+    const unsigned lds0 = lds_addr(kv_lds);
+    auto issue = [&](int tile, int buf) {
+        const bf16_t* src = base + (size_t)tile * KT2 * C3;          // wave-uniform
+#pragma unroll
+        for (int j = 0; j < PER_HALF; ++j) {
+            const int i = wave + NW * j;
+            glds16s(src, koff[j], __builtin_amdgcn_readfirstlane(lds0 + buf * TILE_BYTES + i * 1024));
+            glds16s(src, voff[j], __builtin_amdgcn_readfirstlane(lds0 + buf * TILE_BYTES + K_BYTES + i * 1024));
         }
     };
-    auto stash = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < PER_THREAD; ++i) {
-            const int c = tid + i * NT;
-            const int r = c / CHUNKS, ch = c % CHUNKS;
-            *reinterpret_cast<u32x4*>(k_lds + buf * K_BYTES + r * ROW + ((ch ^ ((r >> 1) & 7)) << 4)) = kreg[i];
-            *reinterpret_cast<u32x4*>(v_lds + buf * V_BYTES + r * VROW + ch * 16) = vreg[i];
-        }
-    };
-    fetch(0);
-    stash(0);
-    __syncthreads();
-
     const int ntiles = L / KT2;
+    issue(0, 0);
+    issue(ntiles > 1 ? 1 : 0, 1);
+
+    // this lane's V^T gather: rows 4*(g>>1) + q (+ 8) of a 16-key step, 8 bytes at d = 32*dh + 16*(g&1) + 4*pp, the
+    // 64-byte half picked against the row pair's swap
+    int vlane[2];
+    {
+        const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+        const int sw = (q >> 1) & 1;
+#pragma unroll
+        for (int dh = 0; dh < 2; ++dh)
+            vlane[dh] = (4 * (g >> 1) + q) * ROW + ((dh ^ sw) << 6) + (g & 1) * 32 + 8 * pp;
+    }
+
     for (int t = 0; t < ntiles; ++t) {
-        const unsigned char* kb = k_lds + (t & 1) * K_BYTES;
-        const unsigned char* vb = v_lds + (t & 1) * V_BYTES;
-        // (the last tile fetches itself again and parks it in the idle buffer: no branch around the copies)
-        fetch((t + 1 < ntiles ? t + 1 : t) * KT2);
+        // tile t has landed (the PER_WAVE copies of tile t+1 may still be in flight); after the barrier every wave's
+        // part of it is visible and every wave is done with tile t-1, whose buffer tile t+2 now overwrites
+        dma_wait_upto<PER_WAVE>();
+        __syncthreads();
+        // (past the end the last tile is fetched again into an idle buffer: every wave issues the same number of
+        // copies per tile, which the counted wait relies on)
+        issue(t + 2 < ntiles ? t + 2 : ntiles - 1, (t + 2) % NBUF);
+        const unsigned char* kb = kv_lds + (t % NBUF) * TILE_BYTES;
+        const unsigned char* vb = kb + K_BYTES;
 
         // S^T[key][query] for the two 32-key blocks of the tile
         f32x16 s[2];
@@ -338,21 +365,17 @@ __global__ __launch_bounds__(NW * 64) void attention_bf16_kernel(const bf16_t* _
                 for (int j = 0; j < 8; ++j) pf[j] = (__bf16)s[blk][8 * st + j];
 #pragma unroll
                 for (int dh = 0; dh < 2; ++dh) {
-                    const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
-                    const int dcol = dh * 32 + (g & 1) * 16 + 4 * pp;
-                    const int krow0 = 32 * blk + 16 * st + 4 * (g >> 1) + q;
                     typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
                     typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
-                    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(vb + krow0 * VROW + dcol * 2));
-                    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(vb + (krow0 + 8) * VROW + dcol * 2));
+                    const unsigned char* vp = vb + (32 * blk + 16 * st) * ROW + vlane[dh];
+                    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)vp);
+                    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(vp + 8 * ROW));
                     const bf16x8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                     o[dh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[dh], 0, 0, 0);
                 }
             }
-
-        stash((t + 1) & 1);
-        __syncthreads();     // tile t+1 is visible, and nobody still reads the buffer tile t+2 will overwrite
     }
+    dma_wait_all();          // the copies past the end must not land in LDS that already belongs to another workgroup
 
     const float l = l_run + __shfl_xor(l_run, 32);
     const float inv = 1.0f / l;
@@ -387,11 +410,11 @@ static int attention_impl(const void* qkv, void* out, float* lse, int dtype, int
     static const bool old_form = getenv("MAD_ATTN_OLD") != nullptr;      // tuning aid: the generic kernel for bf16 too
     if (dtype == MAD_BF16 && !old_form) {
         if (L % 128 == 0)
-            hipLaunchKernelGGL((attention_bf16_kernel<4>), dim3(L / 128, heads, B), dim3(256), 0, s, (const bf16_t*)qkv,
-                               (bf16_t*)out, lse, L, heads);
+            hipLaunchKernelGGL((attention_bf16_kernel<4>), dim3((L / 128) * heads * B), dim3(256), 0, s, (const bf16_t*)qkv,
+                               (bf16_t*)out, lse, L, heads, B);
         else
-            hipLaunchKernelGGL((attention_bf16_kernel<2>), dim3(L / 64, heads, B), dim3(128), 0, s, (const bf16_t*)qkv,
-                               (bf16_t*)out, lse, L, heads);
+            hipLaunchKernelGGL((attention_bf16_kernel<2>), dim3((L / 64) * heads * B), dim3(128), 0, s, (const bf16_t*)qkv,
+                               (bf16_t*)out, lse, L, heads, B);
         return check_launch(who);
     }
     if (L % 128 == 0) {
