@@ -212,7 +212,10 @@ constexpr float RESCALE_THR = MAD_ATTN_THR;
 
 __device__ __forceinline__ float max3f(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
 
-template <int NW>
+// QB: 32-query blocks per wave.  With two, every K fragment and every gathered V^T fragment read from LDS feeds two
+// MFMAs, a K/V tile copied into LDS serves twice the queries, and the two blocks' softmax chains are independent
+// instruction streams inside one wave (64 + 64 accumulator registers: two waves per SIMD).
+template <int NW, int QB>
 __global__ __launch_bounds__(NW * 64) void attention_bf16_kernel(const bf16_t* __restrict__ qkv,
                                                                   bf16_t* __restrict__ out,
                                                                   float* __restrict__ lse, int L, int heads, int B) {
@@ -224,8 +227,8 @@ __global__ __launch_bounds__(NW * 64) void attention_bf16_kernel(const bf16_t* _
     // Workgroups are handed to the eight XCDs round-robin by their linear index, and every query block of a
     // (sample, head) reads that pair's whole K and V: the one-dimensional grid is mapped so that all query blocks of
     // a pair run on ONE XCD, whose L2 then holds its K and V once (with the pair as the slow grid dimension eight
-    // XCDs each fetched them from memory, and the kernel ran at the speed of that traffic).
-    const int nq = L / (NW * 32), nbh = heads * B;
+    // XCDs each fetched them from memory).
+    const int nq = L / (NW * 32 * QB), nbh = heads * B;
     int bh, qb;
     if ((nbh & 7) == 0) {
         const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
@@ -235,14 +238,15 @@ __global__ __launch_bounds__(NW * 64) void attention_bf16_kernel(const bf16_t* _
     }
     const int b = bh / heads, head = bh % heads;
     const int C3 = heads * 3 * HD;
-    const int q0 = (qb * NW + wave) * 32;
+    const int q0 = (qb * NW + wave) * 32 * QB;            // this wave's first query; block u holds q0 + 32u ..
     const int qi = lane & 31, fh = lane >> 5;
     const bf16_t* base = qkv + (size_t)b * L * C3 + head * 3 * HD;
 
     // Q fragments (B operand), scaled by 1/sqrt(64): exact in bf16
-    uint4 qf[4];
-    {
-        const bf16_t* qrow = base + (size_t)(q0 + qi) * C3;
+    uint4 qf[QB][4];
+#pragma unroll
+    for (int u = 0; u < QB; ++u) {
+        const bf16_t* qrow = base + (size_t)(q0 + 32 * u + qi) * C3;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             Vec16<bf16_t> v;
@@ -252,15 +256,19 @@ __global__ __launch_bounds__(NW * 64) void attention_bf16_kernel(const bf16_t* _
 #pragma unroll
             for (int i = 0; i < VEC; ++i) f[i] *= 0.125f;
             v.pack(f);
-            qf[kk] = v.raw;
+            qf[u][kk] = v.raw;
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the Q loads: the counted waits below see only the copies
 
-    f32x16 o[2];
+    f32x16 o[QB][2];
+    float m2[QB], l_run[QB];                    // running maximum in exp2 units, running sum
 #pragma unroll
-    for (int e = 0; e < 16; ++e) { o[0][e] = 0.0f; o[1][e] = 0.0f; }
-    float m2 = -1.0e30f, l_run = 0.0f;          // running maximum in exp2 units, running sum
+    for (int u = 0; u < QB; ++u) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { o[u][0][e] = 0.0f; o[u][1][e] = 0.0f; }
+        m2[u] = -1.0e30f; l_run[u] = 0.0f;
+    }
     constexpr float LOG2E = 1.44269504088896340736f;
 
     // A tile is 64 keys x (128 bytes of K + 128 bytes of V) = 16 copy instructions of 8 rows each, PER_WAVE per wave:
@@ -310,59 +318,68 @@ __global__ __launch_bounds__(NW * 64) void attention_bf16_kernel(const bf16_t* _
         const unsigned char* kb = kv_lds + (t % NBUF) * TILE_BYTES;
         const unsigned char* vb = kb + K_BYTES;
 
-        // S^T[key][query] for the two 32-key blocks of the tile
-        f32x16 s[2];
+        // S^T[key][query] for the two 32-key blocks of the tile: one K fragment per (block, k-step), QB products
+        f32x16 s[QB][2];
 #pragma unroll
         for (int blk = 0; blk < 2; ++blk) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) s[blk][e] = 0.0f;
+            for (int u = 0; u < QB; ++u)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) s[u][blk][e] = 0.0f;
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
                 const int ch = 2 * kk + fh;
                 const int r = blk * 32 + qi;
                 const uint4 kf = *reinterpret_cast<const uint4*>(kb + r * ROW + ((ch ^ ((r >> 1) & 7)) << 4));
-                mma_chunk<bf16_t>(s[blk], kf, qf[kk]);
+#pragma unroll
+                for (int u = 0; u < QB; ++u) mma_chunk<bf16_t>(s[u][blk], kf, qf[u][kk]);
             }
         }
 
-        // this lane's query: 32 of the tile's keys here, the other 32 in lane^32
-        float tmax = max3f(s[0][0], s[0][1], s[0][2]);
 #pragma unroll
-        for (int e = 3; e < 15; e += 2) tmax = max3f(tmax, s[0][e], s[0][e + 1]);
-        tmax = max3f(tmax, s[0][15], s[1][0]);
+        for (int u = 0; u < QB; ++u) {
+            // this lane's query: 32 of the tile's keys here, the other 32 in lane^32
+            float tmax = max3f(s[u][0][0], s[u][0][1], s[u][0][2]);
 #pragma unroll
-        for (int e = 1; e < 15; e += 2) tmax = max3f(tmax, s[1][e], s[1][e + 1]);
-        tmax = fmaxf(tmax, s[1][15]);
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
-        const float t2 = tmax * LOG2E;
-        if (__builtin_amdgcn_ballot_w64(t2 > m2 + RESCALE_THR) != 0) {      // wave-uniform
-            const float m_new = fmaxf(m2, t2);
-            const float alpha = __builtin_amdgcn_exp2f(m2 - m_new);
-            l_run *= alpha;
+            for (int e = 3; e < 15; e += 2) tmax = max3f(tmax, s[u][0][e], s[u][0][e + 1]);
+            tmax = max3f(tmax, s[u][0][15], s[u][1][0]);
 #pragma unroll
-            for (int e = 0; e < 16; ++e) { o[0][e] *= alpha; o[1][e] *= alpha; }
-            m2 = m_new;
+            for (int e = 1; e < 15; e += 2) tmax = max3f(tmax, s[u][1][e], s[u][1][e + 1]);
+            tmax = fmaxf(tmax, s[u][1][15]);
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+            const float t2 = tmax * LOG2E;
+            if (__builtin_amdgcn_ballot_w64(t2 > m2[u] + RESCALE_THR) != 0) {      // wave-uniform
+                const float m_new = fmaxf(m2[u], t2);
+                const float alpha = __builtin_amdgcn_exp2f(m2[u] - m_new);
+                l_run[u] *= alpha;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) { o[u][0][e] *= alpha; o[u][1][e] *= alpha; }
+                m2[u] = m_new;
+            }
+            float psum0 = 0.0f, psum1 = 0.0f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                s[u][0][e] = __builtin_amdgcn_exp2f(fmaf(s[u][0][e], LOG2E, -m2[u]));
+                s[u][1][e] = __builtin_amdgcn_exp2f(fmaf(s[u][1][e], LOG2E, -m2[u]));
+                psum0 += s[u][0][e];
+                psum1 += s[u][1][e];
+            }
+            l_run[u] += psum0 + psum1;
         }
-        float psum0 = 0.0f, psum1 = 0.0f;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            s[0][e] = __builtin_amdgcn_exp2f(fmaf(s[0][e], LOG2E, -m2));
-            s[1][e] = __builtin_amdgcn_exp2f(fmaf(s[1][e], LOG2E, -m2));
-            psum0 += s[0][e];
-            psum1 += s[1][e];
-        }
-        l_run += psum0 + psum1;
 
         // O^T[d][query] += sum_key V[key][d] * P^T[key][query]; k-step st of block blk uses accumulator
         // registers 8st..8st+7 as the B fragment: element j of lane half h is key 32blk + 16st + 8(j>>2) + 4h
-        // + (j&3), and the A fragment gathers V^T at those keys with two transposed 4-key x 16-d reads
+        // + (j&3), and the A fragment gathers V^T at those keys with two transposed 4-key x 16-d reads (one gather,
+        // QB products)
 #pragma unroll
         for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
             for (int st = 0; st < 2; ++st) {
-                bf16x8 pf;
+                bf16x8 pf[QB];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) pf[j] = (__bf16)s[blk][8 * st + j];
+                for (int u = 0; u < QB; ++u)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) pf[u][j] = (__bf16)s[u][blk][8 * st + j];
 #pragma unroll
                 for (int dh = 0; dh < 2; ++dh) {
                     typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
@@ -371,30 +388,36 @@ __global__ __launch_bounds__(NW * 64) void attention_bf16_kernel(const bf16_t* _
                     const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)vp);
                     const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(vp + 8 * ROW));
                     const bf16x8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                    o[dh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[dh], 0, 0, 0);
+#pragma unroll
+                    for (int u = 0; u < QB; ++u)
+                        o[u][dh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[u], o[u][dh], 0, 0, 0);
                 }
             }
     }
     dma_wait_all();          // the copies past the end must not land in LDS that already belongs to another workgroup
 
-    const float l = l_run + __shfl_xor(l_run, 32);
-    const float inv = 1.0f / l;
     const int C = heads * HD;
-    // natural-log sum-exp of the query's scaled scores (what the backward rebuilds the probabilities from)
-    if (lse && fh == 0) lse[((size_t)b * heads + head) * L + q0 + qi] = m2 * 0.69314718055994530942f + __logf(l);
-    bf16_t* orow = out + ((size_t)b * L + q0 + qi) * C + head * HD;
 #pragma unroll
-    for (int dh = 0; dh < 2; ++dh)
+    for (int u = 0; u < QB; ++u) {
+        const float l = l_run[u] + __shfl_xor(l_run[u], 32);
+        const float inv = 1.0f / l;
+        const int qrow = q0 + 32 * u + qi;
+        // natural-log sum-exp of the query's scaled scores (what the backward rebuilds the probabilities from)
+        if (lse && fh == 0) lse[((size_t)b * heads + head) * L + qrow] = m2[u] * 0.69314718055994530942f + __logf(l);
+        bf16_t* orow = out + ((size_t)b * L + qrow) * C + head * HD;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int d = dh * 32 + 8 * g + 4 * fh;
-            ushort4 pk;
-            pk.x = f32_to_bf16(o[dh][4 * g + 0] * inv);
-            pk.y = f32_to_bf16(o[dh][4 * g + 1] * inv);
-            pk.z = f32_to_bf16(o[dh][4 * g + 2] * inv);
-            pk.w = f32_to_bf16(o[dh][4 * g + 3] * inv);
-            *reinterpret_cast<ushort4*>(orow + d) = pk;
-        }
+        for (int dh = 0; dh < 2; ++dh)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int d = dh * 32 + 8 * g + 4 * fh;
+                ushort4 pk;
+                pk.x = f32_to_bf16(o[u][dh][4 * g + 0] * inv);
+                pk.y = f32_to_bf16(o[u][dh][4 * g + 1] * inv);
+                pk.z = f32_to_bf16(o[u][dh][4 * g + 2] * inv);
+                pk.w = f32_to_bf16(o[u][dh][4 * g + 3] * inv);
+                *reinterpret_cast<ushort4*>(orow + d) = pk;
+            }
+    }
 }
 
 }  // namespace mad
@@ -409,11 +432,17 @@ static int attention_impl(const void* qkv, void* out, float* lse, int dtype, int
     hipStream_t s = (hipStream_t)stream;
     static const bool old_form = getenv("MAD_ATTN_OLD") != nullptr;      // tuning aid: the generic kernel for bf16 too
     if (dtype == MAD_BF16 && !old_form) {
-        if (L % 128 == 0)
-            hipLaunchKernelGGL((attention_bf16_kernel<4>), dim3((L / 128) * heads * B), dim3(256), 0, s, (const bf16_t*)qkv,
+        // two query blocks per wave (256 queries per workgroup) where that still gives every CU its two workgroups
+        static const int qb_sel = getenv("MAD_ATTN_QB") ? atoi(getenv("MAD_ATTN_QB")) : 0;    // tuning aid: 1 / 2 forced
+        const bool two = qb_sel ? qb_sel == 2 : (size_t)(L / 256) * heads * B >= 512;
+        if (L % 256 == 0 && two)
+            hipLaunchKernelGGL((attention_bf16_kernel<4, 2>), dim3((L / 256) * heads * B), dim3(256), 0, s, (const bf16_t*)qkv,
+                               (bf16_t*)out, lse, L, heads, B);
+        else if (L % 128 == 0)
+            hipLaunchKernelGGL((attention_bf16_kernel<4, 1>), dim3((L / 128) * heads * B), dim3(256), 0, s, (const bf16_t*)qkv,
                                (bf16_t*)out, lse, L, heads, B);
         else
-            hipLaunchKernelGGL((attention_bf16_kernel<2>), dim3((L / 64) * heads * B), dim3(128), 0, s, (const bf16_t*)qkv,
+            hipLaunchKernelGGL((attention_bf16_kernel<2, 1>), dim3((L / 64) * heads * B), dim3(128), 0, s, (const bf16_t*)qkv,
                                (bf16_t*)out, lse, L, heads, B);
         return check_launch(who);
     }
