@@ -211,6 +211,19 @@ constexpr int KT2 = 64;
 constexpr float RESCALE_THR = MAD_ATTN_THR;
 
 __device__ __forceinline__ float max3f(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
+// max / sum of a value with the one held by lane ^ 32: v_permlane32_swap exchanges the upper half of its first
+// operand with the lower half of its second, so with both operands x one result holds x of lanes 0..31 twice and
+// the other x of lanes 32..63 twice
+__device__ __forceinline__ float halves_max(float x) {
+    const unsigned xi = __float_as_uint(x);
+    const auto r = __builtin_amdgcn_permlane32_swap(xi, xi, false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float halves_sum(float x) {
+    const unsigned xi = __float_as_uint(x);
+    const auto r = __builtin_amdgcn_permlane32_swap(xi, xi, false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
 
 // QB: 32-query blocks per wave.  With two, every K fragment and every gathered V^T fragment read from LDS feeds two
 // MFMAs, a K/V tile copied into LDS serves twice the queries, and the two blocks' softmax chains are independent
@@ -339,14 +352,19 @@ __global__ __launch_bounds__(NW * 64) void attention_bf16_kernel(const bf16_t* _
 #pragma unroll
         for (int u = 0; u < QB; ++u) {
             // this lane's query: 32 of the tile's keys here, the other 32 in lane^32
-            float tmax = max3f(s[u][0][0], s[u][0][1], s[u][0][2]);
+            // (four independent chains of three-input maxima, then their maximum: a third of one chain's depth; the
+            // two halves of the query's keys meet through v_permlane32_swap, one vector instruction, no LDS trip)
+            float c4[4];
 #pragma unroll
-            for (int e = 3; e < 15; e += 2) tmax = max3f(tmax, s[u][0][e], s[u][0][e + 1]);
-            tmax = max3f(tmax, s[u][0][15], s[u][1][0]);
-#pragma unroll
-            for (int e = 1; e < 15; e += 2) tmax = max3f(tmax, s[u][1][e], s[u][1][e + 1]);
-            tmax = fmaxf(tmax, s[u][1][15]);
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+            for (int c = 0; c < 4; ++c) {
+                const int blk = c >> 1, e0 = 8 * (c & 1);
+                c4[c] = max3f(s[u][blk][e0], s[u][blk][e0 + 1], s[u][blk][e0 + 2]);
+                c4[c] = max3f(c4[c], s[u][blk][e0 + 3], s[u][blk][e0 + 4]);
+                c4[c] = max3f(c4[c], s[u][blk][e0 + 5], s[u][blk][e0 + 6]);
+                c4[c] = fmaxf(c4[c], s[u][blk][e0 + 7]);
+            }
+            float tmax = fmaxf(max3f(c4[0], c4[1], c4[2]), c4[3]);
+            tmax = halves_max(tmax);
             const float t2 = tmax * LOG2E;
             if (__builtin_amdgcn_ballot_w64(t2 > m2[u] + RESCALE_THR) != 0) {      // wave-uniform
                 const float m_new = fmaxf(m2[u], t2);
@@ -399,7 +417,7 @@ __global__ __launch_bounds__(NW * 64) void attention_bf16_kernel(const bf16_t* _
     const int C = heads * HD;
 #pragma unroll
     for (int u = 0; u < QB; ++u) {
-        const float l = l_run[u] + __shfl_xor(l_run[u], 32);
+        const float l = halves_sum(l_run[u]);
         const float inv = 1.0f / l;
         const int qrow = q0 + 32 * u + qi;
         // natural-log sum-exp of the query's scaled scores (what the backward rebuilds the probabilities from)
@@ -433,8 +451,10 @@ static int attention_impl(const void* qkv, void* out, float* lse, int dtype, int
     static const bool old_form = getenv("MAD_ATTN_OLD") != nullptr;      // tuning aid: the generic kernel for bf16 too
     if (dtype == MAD_BF16 && !old_form) {
         // two query blocks per wave (256 queries per workgroup) where that still gives every CU its two workgroups
-        static const int qb_sel = getenv("MAD_ATTN_QB") ? atoi(getenv("MAD_ATTN_QB")) : 0;    // tuning aid: 1 / 2 forced
-        const bool two = qb_sel ? qb_sel == 2 : (size_t)(L / 256) * heads * B >= 512;
+        // (measured: a gain at L = 1024, a loss at L = 256, where a (sample, head) is then a single workgroup)
+        const char* qb_env = getenv("MAD_ATTN_QB");                                    // tuning / test aid: 1 / 2 forced
+        const int qb_sel = qb_env ? atoi(qb_env) : 0;
+        const bool two = qb_sel ? qb_sel == 2 : (L >= 512 && (size_t)(L / 256) * heads * B >= 512);
         if (L % 256 == 0 && two)
             hipLaunchKernelGGL((attention_bf16_kernel<4, 2>), dim3((L / 256) * heads * B), dim3(256), 0, s, (const bf16_t*)qkv,
                                (bf16_t*)out, lse, L, heads, B);

@@ -305,10 +305,16 @@ def test_groupnorm(dev, case, dt):
 
 
 # ------------------------------------------------------------------------------ attention
-@pytest.mark.parametrize("B,L,heads", [(2, 64, 1), (1, 256, 2), (2, 1024, 4), (3, 64, 12)])
+@pytest.mark.parametrize("B,L,heads", [(2, 64, 1), (1, 256, 2), (2, 1024, 4), (3, 64, 12), (8, 256, 3)])
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
-def test_attention(dev, B, L, heads, dt):
+@pytest.mark.parametrize("qb", ["1", "2"])
+def test_attention(dev, B, L, heads, dt, qb, monkeypatch):
+    """qb: one or two 32-query blocks per wave of the bf16 kernel (two needs L a multiple of 256); (8, 256, 3) has a
+    multiple of eight (sample, head) pairs, the case whose grid is mapped XCD by XCD."""
     from mad_amd import ops
+    if qb == "2" and (dt != torch.bfloat16 or L % 256):
+        pytest.skip("two query blocks per wave: bf16, L a multiple of 256")
+    monkeypatch.setenv("MAD_ATTN_QB", qb)
     side = int(math.isqrt(L))
     q, k, v = (_rand((B, heads, L, 64), s, 1.3) for s in (1, 2, 3))
     k[0, 0, 5] *= 6.0                                        # one dominant key: forces max rescaling mid-loop
