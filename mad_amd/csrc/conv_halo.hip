@@ -139,7 +139,7 @@ template <int BN, int TW> constexpr int halo_lds_bytes() {
 // PRE: the coefficient table holds (a, d) * -log2(e) and the weights carry a factor -ln(2): the loader computes
 // u = x*a' + d' and u / (1 + 2^u), which is -log2(e) * silu(x*a + d), one multiply-add per element less.
 template <typename T, bool FUSE, int WM, int WN, int TN, bool OUT_NCHW, bool SKIP, bool GSTAT, int TW = 16, bool PRE = false>
-__global__ __launch_bounds__(64 * WM * WN, WM * WN / (TW / 16) / 2) void conv3x3_halo_kernel(HaloArgs a) {
+__global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_halo_kernel(HaloArgs a) {
     static_assert(!PRE || (FUSE && !OUT_NCHW && !GSTAT), "the prescaled form belongs to the loader transform");
     constexpr int NWAVES = WM * WN, NT = 64 * NWAVES;
     static_assert(NWAVES == 4 || NWAVES == 8, "4 or 8 waves");
@@ -1098,6 +1098,14 @@ static int conv3x3_fused_impl(const void* x1, int C1, const void* x2, int C2, co
     bool wide_ok = wide_fits && !coef && Cout >= 256 && B * (W / 32) * a.tiles_y * (Cout / 128) >= 256;
     if (const char* f = getenv("MAD_HALO_WIDE"))              // tuning / test aid: 0 = never, 2 = wherever it fits
         wide_ok = atoi(f) == 2 ? wide_fits : (wide_ok && atoi(f) != 0);
+    // 256 output channels per workgroup on eight waves (2 x 4, each wave 128 pixels x 64 channels as in the four-wave
+    // form; one workgroup per CU): the staged halo and its loader transform serve twice the channels.  Measured
+    // +3 % (128x128, 256 channels) to +9 % (32x32, 512 channels) where such workgroups still cover every CU, -25 %
+    // where they do not.  The results equal the 128-channel form's to the last bit.
+    const bool bn256_fits = pre && !gn && SC1 == 0 && dtype == MAD_BF16 && mode == 128 && Cout % 256 == 0;
+    bool bn256 = bn256_fits && B * a.tiles_x * a.tiles_y * (Cout / 256) >= 256;
+    if (const char* f = getenv("MAD_HALO_BN256"))            // tuning / test aid: 0 = never, 2 = wherever it fits
+        bn256 = atoi(f) == 2 ? bn256_fits : (bn256 && atoi(f) != 0);
     auto run = [&](bool narrow) -> int {
         if (wide_ok && !narrow) {
             if (SC1 > 0)
@@ -1114,6 +1122,8 @@ static int conv3x3_fused_impl(const void* x1, int C1, const void* x2, int C2, co
             return coef ? launch_halo<T_, true, 2, 2, TN_, false, true>(a, s, what)                   \
                         : launch_halo<T_, false, 2, 2, TN_, false, true>(a, s, what);                 \
         }                                                                                             \
+        if (pre && bn256 && TN_ == 2 && sizeof(T_) == 2)                                              \
+            return launch_halo<bf16_t, true, 2, 4, 2, false, false, false, 16, true>(a, s, what);     \
         if (pre) return launch_halo<T_, true, 2, 2, TN_, false, false, false, 16, true>(a, s, what);  \
         return coef ? launch_halo<T_, true, 2, 2, TN_, false>(a, s, what)                             \
                     : launch_halo<T_, false, 2, 2, TN_, false>(a, s, what);                           \
@@ -1133,7 +1143,7 @@ static int conv3x3_fused_impl(const void* x1, int C1, const void* x2, int C2, co
         a.n_off = Cout - 64; a.ntiles_n = 1;
         return run(true);
     }
-    a.ntiles_n = Cout / mode;
+    a.ntiles_n = bn256 ? Cout / 256 : Cout / mode;
     return run(mode == 64);
 }
 

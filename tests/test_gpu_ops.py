@@ -337,25 +337,33 @@ FUSED_CASES = [
     (1, 64, 160, 0, 128, True, False, "same", True),      # 5 bf16 chunks / 10 fp32 chunks
     (1, 32, 96, 0, 192, True, False, "same", True),       # Cout an odd multiple of 64
     (2, 32, 64, 32, 320, True, False, "same", True),      # 2 x 128 + 64 output channels, two sources
+    (1, 32, 64, 0, 256, True, False, "same", True),       # one 256-channel workgroup column ("256")
+    (1, 32, 96, 32, 512, True, True, "up", True),         # two of them, two sources, nearest x2
 ]
 
 
 @pytest.mark.parametrize("case", FUSED_CASES)
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("bn", ["128", "64", "192", "128w", "192w"])
+@pytest.mark.parametrize("bn", ["128", "64", "192", "128w", "192w", "256"])
 @pytest.mark.parametrize("fmt", ["plain", "tiled", "tiled+pre"])
 def test_conv3x3_fused(dev, case, dt, bn, fmt, monkeypatch):
     """Both workgroup widths (128 and 64 output channels) of the halo-tile kernel, ("192") the split of an
-    odd multiple of 64 channels over a wide and a narrow launch, and ("w") the 16x32-pixel eight-wave tiles
-    forced wherever they fit (bf16, width a multiple of 32, 128-channel workgroups).  fmt: the weights as
+    odd multiple of 64 channels over a wide and a narrow launch, ("w") the 16x32-pixel eight-wave tiles
+    forced wherever they fit (bf16, width a multiple of 32, 128-channel workgroups), and ("256") the eight-wave
+    256-channel workgroups of the prescaled loader-transform form forced likewise.  fmt: the weights as
     (Cout,3,3,Cin), tile by tile, and tile by tile with the loader transform in its prescaled form (coefficients
     times -log2(e), weights times -ln(2)): the same convolution every time."""
     from mad_amd import _lib, ops
     wide = bn.endswith("w")
     bn = bn.rstrip("w")
+    B, H, C1, C2, Cout, fuse, up, res, want_stats = case
+    monkeypatch.setenv("MAD_HALO_BN256", "2" if bn == "256" else "0")
+    if bn == "256":
+        if dt != torch.bfloat16 or fmt != "tiled+pre" or not fuse or Cout % 256:
+            pytest.skip("256-channel workgroups: bf16, prescaled loader transform, whole 256-channel columns")
+        bn = "128"
     monkeypatch.setenv("MAD_HALO_BN", bn)
     monkeypatch.setenv("MAD_HALO_WIDE", "2" if wide else "0")
-    B, H, C1, C2, Cout, fuse, up, res, want_stats = case
     if bn == "192" and Cout % 128 != 64:
         pytest.skip("the split applies to odd multiples of 64 channels")
     if wide and (dt != torch.bfloat16 or H % 32):
