@@ -1102,7 +1102,7 @@ static int conv3x3_fused_impl(const void* x1, int C1, const void* x2, int C2, co
     // form; one workgroup per CU): the staged halo and its loader transform serve twice the channels.  Measured
     // +3 % (128x128, 256 channels) to +9 % (32x32, 512 channels) where such workgroups still cover every CU, -25 %
     // where they do not.  The results equal the 128-channel form's to the last bit.
-    const bool bn256_fits = pre && !gn && SC1 == 0 && dtype == MAD_BF16 && mode == 128 && Cout % 256 == 0;
+    const bool bn256_fits = pre && !gn && dtype == MAD_BF16 && mode == 128 && Cout % 256 == 0;
     bool bn256 = bn256_fits && B * a.tiles_x * a.tiles_y * (Cout / 256) >= 256;
     if (const char* f = getenv("MAD_HALO_BN256"))            // tuning / test aid: 0 = never, 2 = wherever it fits
         bn256 = atoi(f) == 2 ? bn256_fits : (bn256 && atoi(f) != 0);
@@ -1118,6 +1118,8 @@ static int conv3x3_fused_impl(const void* x1, int C1, const void* x2, int C2, co
     do {                                                                                              \
         if (gn) return launch_halo<T_, false, 2, 2, TN_, false, false, true>(a, s, what);             \
         if (SC1 > 0) {                                                                                \
+            if (pre && bn256 && TN_ == 2 && sizeof(T_) == 2)                                          \
+                return launch_halo<bf16_t, true, 2, 4, 2, false, true, false, 16, true>(a, s, what);  \
             if (pre) return launch_halo<T_, true, 2, 2, TN_, false, true, false, 16, true>(a, s, what); \
             return coef ? launch_halo<T_, true, 2, 2, TN_, false, true>(a, s, what)                   \
                         : launch_halo<T_, false, 2, 2, TN_, false, true>(a, s, what);                 \

@@ -428,17 +428,22 @@ def test_conv3x3_fused(dev, case, dt, bn, fmt, monkeypatch):
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("bn", ["128", "64", "128w"])
+@pytest.mark.parametrize("bn", ["128", "64", "128w", "256"])
 @pytest.mark.parametrize("case", [(2, 32, 64, 64, 32, 128), (1, 16, 128, 96, 0, 192), (1, 64, 64, 32, 64, 256)])
 @pytest.mark.parametrize("fmt", ["plain", "tiled+pre"])
 def test_conv3x3_fused_projection(dev, case, dt, bn, fmt, monkeypatch):
-    """conv1 + the residual branch's 1x1 projection of the (two-source) block input in one launch (fmt as in
+    """conv1 + the residual branch's 1x1 projection of the (two-source) block input in one launch (fmt and bn as in
     test_conv3x3_fused; the projection's weights are never scaled)."""
     from mad_amd import _lib, ops
     monkeypatch.setenv("MAD_HALO_WIDE", "2" if bn.endswith("w") else "0")
     bn = bn.rstrip("w")
-    monkeypatch.setenv("MAD_HALO_BN", bn)
     B, H, C, S1, S2, Cout = case
+    monkeypatch.setenv("MAD_HALO_BN256", "2" if bn == "256" else "0")
+    if bn == "256":
+        if dt != torch.bfloat16 or fmt != "tiled+pre" or Cout % 256:
+            pytest.skip("256-channel workgroups: bf16, prescaled loader transform, whole 256-channel columns")
+        bn = "128"
+    monkeypatch.setenv("MAD_HALO_BN", bn)
     h = _rand((B, C, H, H), 1, 1.2)
     s1, s2 = _rand((B, S1, H, H), 2), (_rand((B, S2, H, H), 3) if S2 else None)
     w = _rand((Cout, C, 3, 3), 4, 1.0 / math.sqrt(C * 9))
