@@ -164,9 +164,11 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     from mad_amd import ops
+    from mad_amd.buildid import check_library_is_current
     from mad_amd.config import load_cfg
     from mad_amd.model import build_model
     from mad_amd.synthetic import synthetic_faces, synthetic_parsing_map
+    build_id = check_library_is_current()          # a library built from other sources is not measured
     from mad_amd.translation import TranslationDiffusion
 
     cfg = load_cfg(args.config)
@@ -309,7 +311,7 @@ def main():
             "value": value, "unit": "images/s", "n_gpus": world, "steps": steps, "steps_requested": args.steps,
             "warmup": args.warmup, "warmup_num_of_step": s_warm if args.warmup else None,
             "time_budget_s": round(budget, 1), "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+            "vs_baseline": None, "dtype": args.precision, "data": "synthetic", "build_id": build_id,
             "config": {"workload": f"{os.path.basename(args.config)} "
                                    + ("makeup removal (noise encoding + regeneration), " if args.workload == "removal"
                                       else "makeup transfer (noise encoding + regeneration from a synthetic guide, "

@@ -31,6 +31,10 @@ extern "C" {
 
 int mad_version(void);
 const char* mad_last_error(void);
+/* Hash of the native sources this library was compiled from (mad_amd/buildid.py computes the same hash from the
+ * files): lets a caller refuse a binary that does not belong to its source tree.  No counterpart in the reference,
+ * which has no native code. */
+const char* mad_build_id(void);
 
 /* ------------------------------------------------------------------ sampler (NCHW fp32) ---- */
 
@@ -89,6 +93,10 @@ int mad_masked_copy(float* dst, const float* src, const float* mask, int B, int 
  * Replaces the tensor branch of process_mask + tensor_dilate (translation.py:54-58, 234-273). */
 int mad_keep_mask(const uint8_t* label_map, float* keep, int H, int W, const int32_t* comps,
                   int ncomps, int dilate, void* stream);
+/* The same for a stack of B label maps (B,H,W) -> (B,H,W) in one launch: the batched form of the per-image call
+ * the reference makes (generate_transfer.py:33-91 translates one pair per call; a batch needs one mask per image). */
+int mad_keep_mask_batch(const uint8_t* label_maps, float* keep, int B, int H, int W, const int32_t* comps,
+                        int ncomps, int dilate, void* stream);
 
 /* ------------------------------------------------------------------ denoiser pieces -------- */
 
@@ -176,8 +184,10 @@ int mad_conv2d_ws(const void* x1, int C1, const void* x2, int C2, const void* w,
  *   stats[b, tile, n, 0/1] = sum / sum of squares of y over the 16x16 tile (tile = ty*(W/16)+tx);
  *   stats may be NULL.  mad_gn_finalize consumes it with nsplit = (H/16)*(W/16).  In bf16 the sums are
  *   taken per channel PAIR: slot n = 2i holds the sums over channels 2i and 2i+1, slot 2i+1 holds zeros
- *   (the GroupNorm that consumes them must have an even number of channels per group, as every
- *   GroupNorm of the reference has: model.py:174-181).
+ *   PRECONDITION on the caller: a GroupNorm that consumes them must have an EVEN number of channels per group
+ *   (groups hold whole pairs); the reference's rule num_groups = min(32, C/4) (model.py:174-181) gives that for
+ *   every channel count that is a multiple of 64, not for all (C = 160: five per group) -- nothing in
+ *   mad_gn_finalize can detect a violation, so a caller with odd groups takes the statistics with mad_gn_partial.
  * x is the concatenation of x1 (C1) and x2 (C2), NHWC at (H,W), or at (H/2,W/2) when `upsample`.
  * C1, C2 multiples of 32 (bf16) / 16 (fp32).
  * act is a set of bits:

@@ -10,7 +10,9 @@ import os
 from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmad_hip.so")
+# MAD_LIB_PATH selects another build of the library (the A/B scripts under tools/ set it): the product file is never
+# swapped out from under a later run
+LIB_PATH = os.environ.get("MAD_LIB_PATH") or os.path.join(_HERE, "libmad_hip.so")
 
 MAD_BF16, MAD_F32 = 0, 1
 ALGO_DDPM, ALGO_DDIM = 0, 1
@@ -36,11 +38,13 @@ class SamplerCoef(Structure):
 SIGNATURES = {
     "mad_version": (c_int, []),
     "mad_last_error": (c_char_p, []),
+    "mad_build_id": (c_char_p, []),
     "mad_sampler_update": (c_int, [POINTER(SamplerCoef)] + [c_void_p] * 8 + [c_int] * 5 + [c_void_p]),
     "mad_add_noise": (c_int, [c_void_p] * 4 + [c_float, c_float] + [c_int] * 5 + [c_void_p]),
     "mad_finalize_image": (c_int, [c_void_p, c_void_p, c_int, c_size_t, c_void_p]),
     "mad_masked_copy": (c_int, [c_void_p] * 3 + [c_int] * 5 + [c_void_p]),
     "mad_keep_mask": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p]),
+    "mad_keep_mask_batch": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p]),
     "mad_linear_f32": (c_int, [c_void_p] * 4 + [c_int] * 6 + [c_void_p]),
     "mad_pos_embedding": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "mad_conv_in": (c_int, [c_void_p] * 4 + [c_int] * 6 + [c_void_p]),

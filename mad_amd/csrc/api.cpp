@@ -1,4 +1,4 @@
-// Error reporting and version of libmad_hip.so.
+// Error reporting, version and build identity of libmad_hip.so.
 #include "common.h"
 
 #include <string.h>
@@ -25,5 +25,10 @@ int check_launch(const char* what) {
 
 }  // namespace mad
 
+#ifndef MAD_BUILD_ID
+#error "MAD_BUILD_ID is set by the Makefile (hash of the native sources, mad_amd/buildid.py)"
+#endif
+
 extern "C" int mad_version(void) { return 1; }
+extern "C" const char* mad_build_id(void) { return MAD_BUILD_ID; }
 extern "C" const char* mad_last_error(void) { return mad::g_err; }

@@ -55,10 +55,9 @@ __device__ __forceinline__ int acc_row(int j, int lane) { return (j & 3) + 8 * (
 // is the wave-uniform byte address `lds_wave_base` + lane*16; the global source is per lane.
 // Issued from inline asm so the compiler does not serialise it against the LDS reads of the
 // tile being multiplied: the caller waits with dma_wait_all() before the barrier that publishes
-// the tile.  M0 carries the LDS base and is left holding it: M0 is a reserved register that the compiler never
-// allocates, and nothing it generates for these kernels reads M0 (LDS instructions take no M0 on gfx9 and later;
-// no indexed register moves, GWS or messages are used), so the two scalar moves per copy that saving and
-// restoring it cost are not spent.
+// the tile.  M0 carries the LDS base and is left holding it (no save / restore: two scalar moves per copy less);
+// the statement declares M0 clobbered, so the compiler's own uses of M0 (indexed register moves, GWS, messages,
+// which it initialises right in front of each use) are never assumed to survive a copy.
 __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_wave_base) {
     asm volatile(
         "s_mov_b32 m0, %1\n\t"
@@ -66,7 +65,7 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_wave_base)
         "global_load_lds_dwordx4 %0, off"
         :
         : "v"(gsrc), "s"(lds_wave_base)
-        : "memory");
+        : "memory", "m0");
 }
 
 // The same copy with a wave-uniform 64-bit base address (held in scalar registers) and a 32-bit byte offset
@@ -78,7 +77,7 @@ __device__ __forceinline__ void glds16s(const void* sbase, unsigned voff, unsign
         "global_load_lds_dwordx4 %0, %1"
         :
         : "v"(voff), "s"(sbase), "s"(lds_wave_base)
-        : "memory");
+        : "memory", "m0");
 }
 
 __device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }

@@ -142,12 +142,14 @@ __device__ __forceinline__ int reflect(int i, int n) {
     return i;
 }
 
-// One thread per pixel.  near21[v] / near11: is there a pixel with label v (1 or 6) inside the
-// reflect-padded 21x21 / 11x11 window around this pixel.
+// One thread per pixel, blockIdx.y = label map of the stack.  near21[v] / near11: is there a pixel with label v
+// (1 or 6) inside the reflect-padded 21x21 / 11x11 window around this pixel.
 __global__ __launch_bounds__(256) void keep_mask_kernel(const uint8_t* lab, float* keep, int H, int W,
                                                          const int32_t* comps, int ncomps, int dilate) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= H * W) return;
+    lab += (size_t)blockIdx.y * H * W;
+    keep += (size_t)blockIdx.y * H * W;
     const int y = idx / W, x = idx % W;
     bool near21_1 = false, near21_6 = false, near11 = false;
     for (int dy = -10; dy <= 10; ++dy) {
@@ -251,11 +253,17 @@ extern "C" int mad_masked_copy(float* dst, const float* src, const float* mask, 
     return check_launch("mad_masked_copy");
 }
 
+extern "C" int mad_keep_mask_batch(const uint8_t* label_maps, float* keep, int B, int H, int W, const int32_t* comps,
+                                   int ncomps, int dilate, void* stream) {
+    MAD_REQUIRE(label_maps && keep && comps, "mad_keep_mask: null pointer");
+    MAD_REQUIRE(B > 0 && B <= 65535, "mad_keep_mask: B=%d label maps (1..65535)", B);
+    MAD_REQUIRE(H > 10 && W > 10 && ncomps >= 0 && ncomps <= 16, "mad_keep_mask: needs H,W > 10 and <= 16 components");
+    hipLaunchKernelGGL(keep_mask_kernel, dim3((H * W + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, label_maps,
+                       keep, H, W, comps, ncomps, dilate);
+    return check_launch("mad_keep_mask");
+}
+
 extern "C" int mad_keep_mask(const uint8_t* label_map, float* keep, int H, int W, const int32_t* comps, int ncomps,
                              int dilate, void* stream) {
-    MAD_REQUIRE(label_map && keep && comps, "mad_keep_mask: null pointer");
-    MAD_REQUIRE(H > 10 && W > 10 && ncomps >= 0 && ncomps <= 16, "mad_keep_mask: needs H,W > 10 and <= 16 components");
-    hipLaunchKernelGGL(keep_mask_kernel, dim3((H * W + 255) / 256), dim3(256), 0, (hipStream_t)stream, label_map, keep,
-                       H, W, comps, ncomps, dilate);
-    return check_launch("mad_keep_mask");
+    return mad_keep_mask_batch(label_map, keep, 1, H, W, comps, ncomps, dilate, stream);
 }

@@ -129,6 +129,15 @@ class DhariwalUNet(nn.Module):
         if self._packed is not None and self._packed_key == key:
             return self._packed
         s = self.spec
+        if dt == torch.bfloat16:
+            # the bf16 conv epilogues hand the next GroupNorm its statistics per channel PAIR (slot 2i: channels 2i and
+            # 2i+1, slot 2i+1: zeros): correct only when every group holds whole pairs
+            for b in list(s.enc) + list(s.dec):
+                for c in (b.in_channels, b.out_channels):
+                    if (c // gn_groups(c)) % 2:
+                        raise NotImplementedError(
+                            f"{b.name}: GroupNorm over {c} channels has {c // gn_groups(c)} channels per group; the "
+                            "bf16 path takes statistics per channel pair and needs an even count (use precision='fp32')")
         sd = {k: v.detach() for k, v in self.state_dict().items()}
         for v in sd.values():
             if v.device != device:
@@ -323,13 +332,15 @@ class DhariwalUNet(nn.Module):
         # loops pass: `process_label` repeats one class, the loops one timestep) need the embedding once: it is
         # computed as a single row and the per-block affines are read with a row stride of zero.
         uniform = t.numel() == 1 and (not s.label_dim or class_labels is None or class_labels.shape[0] == 1
-                                      or getattr(class_labels, "mad_uniform_rows", False))
+                                      or uniform_rows(class_labels))
         rows_e = 1 if uniform else B
         emb = ops.pos_embedding(t, P["freqs"], rows_e)
         emb = ops.linear_f32(emb, P["map_layer0.weight"], P["map_layer0.bias"], act_out=True)
         if s.label_dim:
             if class_labels is None:
                 class_labels = torch.zeros((1, s.label_dim), device=x.device)
+            if uniform:
+                class_labels = class_labels[:1]               # before any copy: one row is all there is
             lab = class_labels.to(device=x.device, dtype=torch.float32).reshape(-1, s.label_dim)
             if uniform:
                 lab = lab[:1]
@@ -368,6 +379,14 @@ class DhariwalUNet(nn.Module):
             return (ops.conv_out_fused(h.t, P["out.w32"], P["out.b"], s.out_channels, coef=c, act=True),)
         y = ops.gn_apply(h.t, c, act=True)
         return (ops.conv_out(y, P["out.w"], P["out.b"]),)
+
+
+def uniform_rows(labels: Optional[Tensor]) -> bool:
+    """True when every row of a (B, label_dim) label tensor is the SAME memory: a row expanded over the batch
+    (row stride 0), which is what ``TranslationDiffusion.process_label`` returns for an integer class.  The property
+    is structural -- it cannot go stale under an in-place edit (which edits every row alike) and any operation that
+    gives the rows storage of their own (``clone``, ``contiguous``, ``repeat``) removes it."""
+    return labels is not None and labels.ndim == 2 and labels.shape[0] > 1 and labels.stride(0) == 0
 
 
 class _Act:
@@ -412,23 +431,29 @@ class Denoiser(nn.Module):
         kernel is launched on torch's current stream, which is the capturing stream) and replayed on static
         input buffers; the result is copied out so it survives the next replay."""
         P = self.unet._pack(x.device)
+        uniform = uniform_rows(labels)
         if labels is not None:
-            labels = labels.to(device=x.device, dtype=torch.float32).reshape(-1, self.unet.label_dim)
-        key = (tuple(x.shape), x.dtype, time.numel(), None if labels is None else tuple(labels.shape), P["version"])
+            # one shared row stays one row: the static buffer holds it once and the captured evaluation sees it
+            # expanded over the batch again, so a replay takes the single-row embedding path as well
+            labels = (labels[:1] if uniform else labels).to(device=x.device, dtype=torch.float32)
+            labels = labels.reshape(-1, self.unet.label_dim)
+        key = (tuple(x.shape), x.dtype, time.numel(), None if labels is None else tuple(labels.shape), uniform,
+               P["version"])
         ent = self._graphs.get(key)
         if ent is None:
             self._graphs = {k: v for k, v in self._graphs.items() if k[-1] == P["version"]}   # drop graphs of old weights
             sx, st = x.clone(), time.clone()
             sl = None if labels is None else labels.clone()
+            sl_in = sl.expand(x.shape[0], -1) if uniform else sl
             side = torch.cuda.Stream(device=x.device)
             side.wait_stream(torch.cuda.current_stream(x.device))
             with torch.cuda.stream(side):
                 for _ in range(2):                       # first launches set kernel attributes: not capturable
-                    self.unet(sx, st, sl)
+                    self.unet(sx, st, sl_in)
             torch.cuda.current_stream(x.device).wait_stream(side)
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
-                out = self.unet(sx, st, sl)[0]
+                out = self.unet(sx, st, sl_in)[0]
             ent = self._graphs[key] = (graph, sx, st, sl, out)
         graph, sx, st, sl, out = ent
         sx.copy_(x)

@@ -149,15 +149,23 @@ def masked_copy_(dst: Tensor, src: Tensor, mask: Tensor) -> Tensor:
 
 
 def keep_mask(label_map: Tensor, comps: Sequence[int], dilate: bool = True) -> Tensor:
-    """label_map (H,W) uint8 on the GPU -> (1,H,W) fp32 keep-mask; comps already priority-sorted."""
+    """label_map (H,W) uint8 on the GPU -> (1,H,W) fp32 keep-mask, or a stack (B,H,W) -> (B,1,H,W) in one launch;
+    comps already priority-sorted."""
     _dev(label_map)
-    if label_map.dtype != torch.uint8 or label_map.dim() != 2:
-        raise ValueError("label_map must be a (H,W) uint8 tensor")
-    H, W = label_map.shape
+    if label_map.dtype != torch.uint8 or label_map.dim() not in (2, 3):
+        raise ValueError("label_map must be a (H,W) or (B,H,W) uint8 tensor")
+    label_map = label_map.contiguous()
+    H, W = label_map.shape[-2:]
     comps_t = torch.tensor(list(comps), dtype=torch.int32, device=label_map.device)
-    out = torch.empty((1, H, W), dtype=torch.float32, device=label_map.device)
-    check(lib.mad_keep_mask(_ptr(label_map), _ptr(out), H, W, _ptr(comps_t), len(comps), int(dilate), _stream()),
-          "mad_keep_mask")
+    if label_map.dim() == 2:
+        out = torch.empty((1, H, W), dtype=torch.float32, device=label_map.device)
+        check(lib.mad_keep_mask(_ptr(label_map), _ptr(out), H, W, _ptr(comps_t), len(comps), int(dilate), _stream()),
+              "mad_keep_mask")
+        return out
+    B = label_map.shape[0]
+    out = torch.empty((B, 1, H, W), dtype=torch.float32, device=label_map.device)
+    check(lib.mad_keep_mask_batch(_ptr(label_map), _ptr(out), B, H, W, _ptr(comps_t), len(comps), int(dilate),
+                                  _stream()), "mad_keep_mask_batch")
     return out
 
 

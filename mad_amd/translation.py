@@ -116,8 +116,7 @@ class TranslationDiffusion:
         maps = self._label_map(mask, size)
         comps = list(component_list or self.BASIC_COMPONENT)
         comps.sort(key=lambda c: COMP_PRIORITY[c])
-        keeps = [ops.keep_mask(maps[i], comps, dilate) for i in range(maps.shape[0])]
-        keep = keeps[0] if len(keeps) == 1 else torch.stack(keeps, 0)
+        keep = ops.keep_mask(maps[0], comps, dilate) if maps.shape[0] == 1 else ops.keep_mask(maps, comps, dilate)
         if return_mask_value:
             return (maps[0] if maps.shape[0] == 1 else maps), keep
         return keep
@@ -125,8 +124,9 @@ class TranslationDiffusion:
     def process_label(self, label, batch_size: int):
         if label is not None and isinstance(label, int):
             label = torch.nn.functional.one_hot(torch.tensor(label), self.num_classes).float()
-            label = label.unsqueeze(0).repeat(batch_size, 1).to(self.device)
-            label.mad_uniform_rows = True      # every row is the same class: the denoiser embeds it once
+            # (B, num_classes) as in the reference, but ONE row expanded over the batch (row stride 0) instead of B
+            # copies: the denoiser sees from the stride that every row is the same class and embeds it once
+            label = label.unsqueeze(0).to(self.device).expand(batch_size, -1)
         return label
 
     def sample_xt(self, input_: Tensor, timesteps, mask: Optional[Tensor] = None) -> Tensor:

@@ -40,3 +40,14 @@ def _ensure_built():
 
 
 _ensure_built()
+
+
+def pytest_sessionstart(session):
+    """Refuse to test a stale binary: the id embedded in libmad_hip.so must be the hash of the native sources in
+    this tree (mad_amd/buildid.py)."""
+    from mad_amd.buildid import check_library_is_current
+    try:
+        bid = check_library_is_current()
+    except RuntimeError as e:
+        pytest.exit(str(e), returncode=3)
+    print(f"libmad_hip.so build id {bid} matches the sources")

@@ -174,6 +174,66 @@ class Adapter:
         return self.net(x, t.to(torch.float32), class_labels)[0]
 
 
+def sampler_goldens(ref_sched):
+    """sampler.npz: ``step`` / ``compute_eps`` / ``ddim_inverse_step`` / ``add_noise`` of both reference schedulers
+    at t in {0, 1, 179, 699, 999} on the 1000- and the 50-step table, for every prediction type the reference
+    accepts (scheduler.py:52-71, 157-176, 251-270, 348-362, 455-469, 547-566), masked and unmasked."""
+    samp = {}
+    T_LIST = [0, 1, 179, 699, 999]
+    shape = (2, 3, 8, 8)
+    for kind, cls in (("ddpm", ref_sched.CustomDDPMScheduler), ("ddim", ref_sched.CustomDDIMScheduler)):
+        sch = cls(num_train_timesteps=1000, prediction_type="epsilon", beta_schedule="linear",
+                  beta_start=1e-4, beta_end=0.02)
+        samp[f"{kind}/alphas_cumprod"] = sch.alphas_cumprod.numpy()
+        for n_steps in (1000, 50):
+            sch.set_timesteps(n_steps)
+            samp[f"{kind}/timesteps_{n_steps}"] = sch.timesteps.numpy()
+            sch.set_inverse_timesteps(n_steps)
+            samp[f"{kind}/inverse_timesteps_{n_steps}"] = sch.timesteps.numpy()
+        for n_steps in (1000, 50):
+            sch.set_timesteps(n_steps)
+            ratio = 1000 // n_steps
+            for t in T_LIST:
+                t = (t // ratio) * ratio
+                key = f"{kind}/n{n_steps}/t{t}"
+                sample = seeded_inputs(shape, 7 * t + 1, 1.5)
+                eps = seeded_inputs(shape, 7 * t + 2)
+                noise = seeded_inputs(shape, 7 * t + 3)
+                orig = seeded_inputs(shape, 7 * t + 4, 0.7)
+                nxt = seeded_inputs(shape, 7 * t + 5, 1.2)
+                mask = (seeded_inputs((1, 8, 8), 7 * t + 6) > 0).float()
+                for nm, v in (("sample", sample), ("eps", eps), ("noise", noise), ("orig", orig),
+                              ("next", nxt), ("mask", mask)):
+                    samp[f"{key}/{nm}"] = v.numpy()
+                for pt in ("epsilon", "sample", "v_prediction"):
+                    sch.config.prediction_type = pt
+                    tt = torch.tensor(t)
+                    r = sch.step(eps, tt, sample, eta=0.01, variance_noise=noise)
+                    samp[f"{key}/{pt}/step"] = r.prev_sample.numpy()
+                    samp[f"{key}/{pt}/x0"] = r.pred_original_sample.numpy()
+                    r = sch.step(eps, tt, sample, eta=0.01, variance_noise=noise,
+                                 original_image=orig, mask=mask)
+                    samp[f"{key}/{pt}/step_masked"] = r.prev_sample.numpy()
+                    if kind == "ddim":
+                        r = sch.step(eps, tt, sample, eta=1.0, variance_noise=noise,
+                                     use_clipped_model_output=True)
+                        samp[f"{key}/{pt}/step_eta1_clipped"] = r.prev_sample.numpy()
+                    if t > 0:
+                        samp[f"{key}/{pt}/compute_eps"] = sch.compute_eps(eps, tt, sample, nxt, eta=0.01).numpy()
+                    if t >= ratio or True:
+                        r = sch.ddim_inverse_step(eps, tt, sample)
+                        samp[f"{key}/{pt}/inverse"] = r.prev_sample.numpy()
+                sch.config.prediction_type = "epsilon"
+                samp[f"{key}/add_noise"] = sch.add_noise(orig, noise, torch.tensor([t])).numpy()
+        if kind == "ddpm":
+            sch.set_timesteps(1000)
+            samp["ddpm/var_1"] = sch._get_variance(1).numpy()
+            samp["ddpm/var_999"] = sch._get_variance(999).numpy()
+    np.savez_compressed(os.path.join(HERE, "sampler.npz"), **samp)
+    print("sampler: keys", len(samp))
+
+
+
 def main():
     install_placeholders()
     sys.path.insert(0, REF)
@@ -220,60 +280,7 @@ def main():
         np.savez_compressed(os.path.join(HERE, f"unet_{tag}.npz"), **out)
         print(f"unet_{tag}: out absmax {y.abs().max():.4f} std {y.std():.4f}")
 
-    # ---------------------------------------------------------------- 2. sampler
-    samp = {}
-    T_LIST = [0, 1, 179, 699, 999]
-    shape = (2, 3, 8, 8)
-    for kind, cls in (("ddpm", ref_sched.CustomDDPMScheduler), ("ddim", ref_sched.CustomDDIMScheduler)):
-        sch = cls(num_train_timesteps=1000, prediction_type="epsilon", beta_schedule="linear",
-                  beta_start=1e-4, beta_end=0.02)
-        samp[f"{kind}/alphas_cumprod"] = sch.alphas_cumprod.numpy()
-        for n_steps in (1000, 50):
-            sch.set_timesteps(n_steps)
-            samp[f"{kind}/timesteps_{n_steps}"] = sch.timesteps.numpy()
-            sch.set_inverse_timesteps(n_steps)
-            samp[f"{kind}/inverse_timesteps_{n_steps}"] = sch.timesteps.numpy()
-        for n_steps in (1000, 50):
-            sch.set_timesteps(n_steps)
-            ratio = 1000 // n_steps
-            for t in T_LIST:
-                t = (t // ratio) * ratio
-                key = f"{kind}/n{n_steps}/t{t}"
-                sample = seeded_inputs(shape, 7 * t + 1, 1.5)
-                eps = seeded_inputs(shape, 7 * t + 2)
-                noise = seeded_inputs(shape, 7 * t + 3)
-                orig = seeded_inputs(shape, 7 * t + 4, 0.7)
-                nxt = seeded_inputs(shape, 7 * t + 5, 1.2)
-                mask = (seeded_inputs((1, 8, 8), 7 * t + 6) > 0).float()
-                for nm, v in (("sample", sample), ("eps", eps), ("noise", noise), ("orig", orig),
-                              ("next", nxt), ("mask", mask)):
-                    samp[f"{key}/{nm}"] = v.numpy()
-                for pt in ("epsilon", "sample"):
-                    sch.config.prediction_type = pt
-                    tt = torch.tensor(t)
-                    r = sch.step(eps, tt, sample, eta=0.01, variance_noise=noise)
-                    samp[f"{key}/{pt}/step"] = r.prev_sample.numpy()
-                    samp[f"{key}/{pt}/x0"] = r.pred_original_sample.numpy()
-                    r = sch.step(eps, tt, sample, eta=0.01, variance_noise=noise,
-                                 original_image=orig, mask=mask)
-                    samp[f"{key}/{pt}/step_masked"] = r.prev_sample.numpy()
-                    if kind == "ddim":
-                        r = sch.step(eps, tt, sample, eta=1.0, variance_noise=noise,
-                                     use_clipped_model_output=True)
-                        samp[f"{key}/{pt}/step_eta1_clipped"] = r.prev_sample.numpy()
-                    if t > 0:
-                        samp[f"{key}/{pt}/compute_eps"] = sch.compute_eps(eps, tt, sample, nxt, eta=0.01).numpy()
-                    if t >= ratio or True:
-                        r = sch.ddim_inverse_step(eps, tt, sample)
-                        samp[f"{key}/{pt}/inverse"] = r.prev_sample.numpy()
-                sch.config.prediction_type = "epsilon"
-                samp[f"{key}/add_noise"] = sch.add_noise(orig, noise, torch.tensor([t])).numpy()
-        if kind == "ddpm":
-            sch.set_timesteps(1000)
-            samp["ddpm/var_1"] = sch._get_variance(1).numpy()
-            samp["ddpm/var_999"] = sch._get_variance(999).numpy()
-    np.savez_compressed(os.path.join(HERE, "sampler.npz"), **samp)
-    print("sampler: keys", len(samp))
+    sampler_goldens(ref_sched)
 
     # ---------------------------------------------------------------- 3. masks
     rng = np.random.RandomState(5)
@@ -464,6 +471,71 @@ def refine_and_inversion_goldens():
     np.savez_compressed(os.path.join(HERE, "trajectory_refine.npz"), **out)
 
 
+def long_chain_goldens():
+    """trajectory_s700.npz: the loop at the length the removal workload runs it (generate_translation.py:25,
+    ``--num-of-step 700``): ``encode`` with start_from_step = 700 on the 1000-step DDPM table (699 chained
+    sampler steps + denoiser evaluations + compute_eps divisions by sigma_t, translation.py:708-754) followed by
+    ``generate`` over the 700 steps (translation.py:756-840), run by the reference's own loops on the tiny
+    denoiser.  Random draws come from ``numpy.random.RandomState(seed).standard_normal`` (a frozen stream), one
+    call per draw in call order, so a test regenerates them instead of storing 8 MB of noise.  Stored: inputs,
+    the two end images, the encoded noise at a few steps and its per-step sum / sum of squares."""
+    install_placeholders()
+    sys.path.insert(0, REF)
+    import modeling.model as ref_model
+    import modeling.scheduler as ref_sched
+    import modeling.translation as ref_trans
+    from mad_amd.config import load_cfg
+    from mad_amd.unet_spec import spec_from_cfg
+
+    torch.set_grad_enabled(False)
+    cfg = load_cfg(os.path.join(REPO, "configs", "model_tiny.yaml"))
+    spec = spec_from_cfg(cfg)
+    net = Adapter(build_ref_unet(ref_model, spec, seed=1))
+    td = ref_trans.TranslationDiffusion.__new__(ref_trans.TranslationDiffusion)
+    td.device, td.num_classes, td.sample_steps = "cpu", 2, 1000
+    td.refine_iterations, td.refine_steps, td.eta, td.null_text = 0, 0, 0.01, None
+    td.scheduler = ref_sched.CustomDDPMScheduler(num_train_timesteps=1000, prediction_type="epsilon",
+                                                 beta_schedule="linear", beta_start=1e-4, beta_end=0.02)
+    start, seed = 700, 20261112
+    image = (seeded_inputs((2, 3, 16, 16), 44) * 0.4).clamp(-0.9, 0.9)
+    mask = (seeded_inputs((1, 16, 16), 11) > 0.3).float()
+    src, tgt = td.process_label(0, 2), td.process_label(1, 2)
+    rs = np.random.RandomState(seed)
+    n_draws = [0]
+    real_randn, real_randn_like = torch.randn, torch.randn_like
+
+    def draw(shape):
+        n_draws[0] += 1
+        return torch.from_numpy(rs.standard_normal(size=tuple(shape)).astype(np.float32))
+
+    def fake_randn(*a, **k):
+        shape = a[0] if len(a) == 1 and not isinstance(a[0], int) else a
+        return draw(shape)
+
+    torch.randn, torch.randn_like = fake_randn, (lambda x, **k: draw(x.shape))
+    try:
+        eps_list = td.encode(image, src, net, start_from_step=start)
+        n_enc = n_draws[0]
+        out_same = td.generate(net, eps_list=eps_list, class_label=src, source_image=image.clone(),
+                               source_mask=None, start_from_step=start)
+        n_same = n_draws[0]
+        out_tgt = td.generate(net, eps_list=eps_list, class_label=tgt, source_image=image.clone(),
+                              source_mask=mask, start_from_step=start)
+    finally:
+        torch.randn, torch.randn_like = real_randn, real_randn_like
+    keep = [0, 1, 2, 100, 350, 600, 697, 698, 699]
+    e64 = eps_list.double()
+    out = {"image": image.numpy(), "mask": mask.numpy(), "start": np.int64(start), "seed": np.int64(seed),
+           "n_draws": np.array([n_enc, n_same - n_enc, n_draws[0] - n_same], dtype=np.int64),
+           "eps_steps": np.array(keep, dtype=np.int64), "eps_at_steps": eps_list[:, keep].numpy(),
+           "eps_sum": e64.sum(dim=(0, 2, 3, 4)).numpy(), "eps_sumsq": (e64 * e64).sum(dim=(0, 2, 3, 4)).numpy(),
+           "out_same_label": out_same.numpy(), "out_target_masked": out_tgt.numpy()}
+    np.savez_compressed(os.path.join(HERE, "trajectory_s700.npz"), **out)
+    print(f"s700: eps_list {tuple(eps_list.shape)}, draws {out['n_draws'].tolist()}, "
+          f"|out_same - image| {float((out_same * 2 - 1 - image).abs().max()):.4f}, "
+          f"noise rms first/last step {float(eps_list[:, 1].std()):.3f} / {float(eps_list[:, -1].std()):.3f}")
+
+
 def synthetic_label_map():
     """The 64x64 face-parsing map of the mask fixtures (ellipses with the labels of BASIC_COMPONENT, hair as a
     label outside it, eye pixels at the border for the reflect padding)."""
@@ -596,8 +668,17 @@ if __name__ == "__main__":
         param_order_golden()
     elif len(sys.argv) > 1 and sys.argv[1] == "transfer":
         transfer_goldens()
+    elif len(sys.argv) > 1 and sys.argv[1] == "s700":
+        long_chain_goldens()
+    elif len(sys.argv) > 1 and sys.argv[1] == "sampler":
+        install_placeholders()
+        sys.path.insert(0, REF)
+        import modeling.scheduler as ref_sched_only
+        torch.set_grad_enabled(False)
+        sampler_goldens(ref_sched_only)
     else:
         main()
         refine_and_inversion_goldens()
         transfer_goldens()
+        long_chain_goldens()
         param_order_golden()

@@ -54,17 +54,50 @@ def test_generate_transfer_cli(tmp_path):
         Image.fromarray(arr).save(img_dir / f"p{i}.png")
         Image.fromarray(arr[::-1].copy()).save(guide_dir / f"p{i}.png")
         Image.fromarray(synthetic_parsing_map(16, seed=i).numpy()).save(par_dir / f"p{i}.png")
-    (tmp_path / "src.txt").write_text("p0.png\np1.png\nnope.png\n")
-    (tmp_path / "tgt.txt").write_text("p2.png\np3.png\np2.png\n")
+    (tmp_path / "src.txt").write_text("p0.png\nnope.png\np1.png\np3.png\n")
+    (tmp_path / "tgt.txt").write_text("p2.png\np2.png\np3.png\np0.png\n")
     out = tmp_path / "out"
     argv = ["--config", os.path.join(REPO, "configs", "model_tiny.yaml"), "--save-folder", str(out),
             "--source-root", str(img_dir), "--target-root", str(img_dir), "--guide-root", str(guide_dir),
             "--source-list", str(tmp_path / "src.txt"), "--target-list", str(tmp_path / "tgt.txt"),
             "--source-label", "1", "--target-label", "0", "--inpainting", "--cam"]
-    gtr.main(argv)
-    assert sorted(os.listdir(out)) == ["pred_0.png", "pred_1.png"]
-    img = np.array(Image.open(out / "pred_1.png"))
+    # pairs go two at a time; the group holding the unreadable pair falls back to pair-by-pair and loses only it
+    gtr.main(argv + ["--batch", "2"])
+    assert sorted(os.listdir(out)) == ["pred_0.png", "pred_2.png", "pred_3.png"]
+    img = np.array(Image.open(out / "pred_2.png"))
     assert img.shape == (16, 16, 3) and img.std() > 0
+
+
+def test_transfer_batch_equals_pair_by_pair():
+    """Stacked sources, guides and label maps through ONE image_translation call give each pair the image it gets
+    alone (same draws per image): what --batch relies on.  fp32 mode, tolerance 1e-5 on [0, 1] images."""
+    from mad_amd.config import load_cfg
+    from mad_amd.model import build_model
+    from mad_amd.synthetic import synthetic_faces, synthetic_parsing_map
+    from mad_amd.translation import TranslationDiffusion
+    dev = torch.device("cuda:0")
+    cfg = load_cfg(os.path.join(REPO, "configs", "model_tiny.yaml"))
+    m = build_model(cfg, precision="fp32")
+    m.unet.init_seeded(2)
+    m = m.to(dev).eval()
+    B, R = 3, 16
+    src, guide = synthetic_faces(B, R, seed=7).to(dev), synthetic_faces(B, R, seed=8).to(dev)
+    maps = torch.stack([synthetic_parsing_map(R, seed=i) for i in range(B)]).to(dev)
+    setup = {4: (0.4, 9), 9: (0.8, 5), 1: (0.8, 7), 6: (0.8, 7)}
+    pool = torch.randn(24, B, 3, R, R, generator=torch.Generator().manual_seed(3)).to(dev)
+
+    def run(rows):
+        td = TranslationDiffusion(cfg, dev)
+        k = iter(range(pool.shape[0]))
+        td.noise_source = lambda shape: pool[next(k)][rows]
+        return td.image_translation(m, m, src[rows].contiguous(), src[rows].contiguous(), 1, 0,
+                                    source_parsing_mask=maps[rows].contiguous(), use_cam=True, inpainting=True,
+                                    inverse_image=guide[rows].contiguous(), comp_weight_step=setup)
+
+    together = run(slice(0, B))
+    for i in range(B):
+        alone = run(slice(i, i + 1))
+        assert float((alone - together[i:i + 1]).abs().max()) < 1e-5, i
 
 
 def test_training_cli(tmp_path):

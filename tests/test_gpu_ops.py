@@ -67,7 +67,7 @@ def test_sampler_golden(dev, kind):
         for t in sorted({(t // ratio) * ratio for t in (0, 1, 179, 699, 999)}):
             key = f"{kind}/n{n}/t{t}"
             T = lambda nm: torch.from_numpy(g[f"{key}/{nm}"]).to(dev)
-            for pt in ("epsilon", "sample"):
+            for pt in ("epsilon", "sample", "v_prediction"):
                 s.config.prediction_type = pt
                 r = s.step(T("eps"), t, T("sample"), eta=0.01, variance_noise=T("noise"), return_pred_original=True)
                 cmp(r.prev_sample, f"{key}/{pt}/step")
@@ -139,6 +139,17 @@ def test_keep_mask_golden(dev):
         if k.startswith("keep_") and k[5].isdigit():
             comps = sorted([int(c) for c in k[5:].split("_")], key=lambda c: COMP_PRIORITY[c])
             assert torch.equal(ops.keep_mask(lab, comps, True).cpu(), torch.from_numpy(g[k])), k
+    # a stack of maps in one launch: every row equals the single-map result (the reference map, its mirror image and
+    # its transpose)
+    stack = torch.stack([lab, lab.flip(1), lab.t().contiguous()]).contiguous()
+    both = ops.keep_mask(stack, basic, True)
+    assert tuple(both.shape) == (3, 1, 64, 64)
+    for i in range(3):
+        assert torch.equal(both[i], ops.keep_mask(stack[i].contiguous(), basic, True)), i
+    assert torch.equal(both[0].cpu(), torch.from_numpy(g["keep_all"]))
+    td = TranslationDiffusion.__new__(TranslationDiffusion)
+    td.device = dev
+    assert torch.equal(td.process_mask(stack, (64, 64)), both)
 
 
 # ------------------------------------------------------------------------------ embedding

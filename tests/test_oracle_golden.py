@@ -75,7 +75,7 @@ def test_sampler_matches_reference(kind):
         for t in sorted({(t // ratio) * ratio for t in (0, 1, 179, 699, 999)}):
             key = f"{kind}/n{n}/t{t}"
             T = lambda nm: torch.from_numpy(g[f"{key}/{nm}"])
-            for pt in ("epsilon", "sample"):
+            for pt in ("epsilon", "sample", "v_prediction"):
                 s.config.prediction_type = pt
                 r = s.step(T("eps"), t, T("sample"), eta=0.01, variance_noise=T("noise"))
                 np.testing.assert_array_equal(r.prev_sample.numpy(), g[f"{key}/{pt}/step"])
@@ -96,7 +96,7 @@ def test_sampler_matches_reference(kind):
             s.config.prediction_type = "epsilon"
             np.testing.assert_array_equal(
                 s.add_noise(T("orig"), T("noise"), torch.tensor([t])).numpy(), g[f"{key}/add_noise"])
-    assert checked >= 16
+    assert checked >= 24
     # the clamp is exercised: some predicted x0 sit exactly on +-1
     assert (np.abs(g[f"{kind}/n1000/t699/epsilon/x0"]) == 1.0).any()
 
@@ -153,6 +153,42 @@ def test_trajectory_matches_reference(kind):
     out = tr.generate(model, eps_list=ref_eps, class_label=tgt, source_image=image,
                       source_mask=torch.from_numpy(g[f"{kind}/mask"]), start_from_step=start)
     assert float((out - torch.from_numpy(g[f"{kind}/out_target_masked"])).abs().max()) < tol
+
+
+def rs_draws(seed):
+    """The frozen numpy stream the S = 700 golden was recorded with: one standard_normal call per draw."""
+    rs = np.random.RandomState(seed)
+    return lambda shape: torch.from_numpy(rs.standard_normal(size=tuple(shape)).astype(np.float32))
+
+
+def test_long_chain_matches_reference():
+    """The loop at the length the removal workload runs it (start_from_step = 700 on the 1000-step DDPM table:
+    699 + 700 denoiser evaluations, /root/reference/generate_translation.py:25, modeling/translation.py:708-840)
+    against the reference's own run of it: encoded noise at the stored steps, its per-step sum of squares over all
+    700 steps, and both end images."""
+    g = load_golden("trajectory_s700.npz")
+    spec, sd, kw = _oracle_unet("model_tiny.yaml", 1)
+    model = lambda x, t, labels: unet_forward(sd, x, t, labels, **kw)
+    start = int(g["start"])
+    image, mask = torch.from_numpy(g["image"]), torch.from_numpy(g["mask"])
+    tr = RefTranslation(RefScheduler("ddpm"), 2, sample_steps=1000, eta=0.01, randn=rs_draws(int(g["seed"])))
+    src, tgt = tr.process_label(0, 2), tr.process_label(1, 2)
+    eps_list = tr.encode(image, src, model, start_from_step=start)
+    assert tuple(eps_list.shape) == (2, start, 3, 16, 16)
+    ref_at = torch.from_numpy(g["eps_at_steps"])
+    worst = max(rel_err(eps_list[:, int(i)], ref_at[:, k]) for k, i in enumerate(g["eps_steps"]))
+    sq = (eps_list.double() ** 2).sum(dim=(0, 2, 3, 4)).numpy()
+    worst_sq = float(np.abs(sq / g["eps_sumsq"] - 1).max())
+    out_same = tr.generate(model, eps_list=eps_list, class_label=src, source_image=image, start_from_step=start)
+    out_tgt = tr.generate(model, eps_list=eps_list, class_label=tgt, source_image=image, source_mask=mask,
+                          start_from_step=start)
+    e_same = float((out_same - torch.from_numpy(g["out_same_label"])).abs().max())
+    e_tgt = float((out_tgt - torch.from_numpy(g["out_target_masked"])).abs().max())
+    print(f"S=700 oracle vs reference: noise rel err at stored steps {worst:.2e}, per-step sum of squares "
+          f"{worst_sq:.2e}, end images {e_same:.2e} / {e_tgt:.2e}")
+    # measured 1.6e-6 / 4e-8 / 9e-7 in the build container; the margins cover another host's fp32 summation order
+    assert worst < 2e-3 and worst_sq < 1e-4
+    assert e_same < 2e-4 and e_tgt < 2e-4
 
 
 def test_refine_loop_matches_reference():

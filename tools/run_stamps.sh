@@ -1,10 +1,9 @@
 #!/bin/bash
-# cycle stamps of one workgroup of the halo conv: tools/run_stamps.sh  (needs mad_amd/libmad_hip_stamps.so)
+# cycle stamps of one workgroup of the halo conv: tools/run_stamps.sh  (needs mad_amd/libmad_hip_stamps.so, selected
+# through MAD_LIB_PATH)
 cd $GRAFT_REPO_ROOT
-cp mad_amd/libmad_hip.so /tmp/base.so
-cp mad_amd/libmad_hip_stamps.so mad_amd/libmad_hip.so
+export MAD_LIB_PATH=$GRAFT_REPO_ROOT/mad_amd/libmad_hip_stamps.so
 for cfg in "256 1 32" "256 1 1" "256 1 2" "256 0 32" "256 0 1"; do
   echo "=== H fuse B = $cfg"
   timeout -k 10 120 python -u tools/halo_stamps.py $cfg 2>&1 | grep -v amdgpu.ids
 done
-cp /tmp/base.so mad_amd/libmad_hip.so
