@@ -153,13 +153,15 @@ def test_trajectory_bf16_end_image_psnr(dev, kind):
     if kind == "ddpm":
         assert p_same >= 40.0 and p_tgt >= 40.0          # measured 91.2 / 79.9 dB
     else:
-        # The 50-step DDIM chain (eta = 0.01: sigma_t ~ 1e-4, twenty-timestep jumps) with THIS random-weight
-        # denoiser is a chaotic map: test_replay_invariant measures a rounding difference growing ~15 % per step
-        # in fp32 (x 1000 over 50 steps, which is why the fp32 goldens agree to 1e-4 and not 1e-7).  bf16's unit
-        # roundoff (4e-3, against fp32's 6e-8) goes through the same growth; measured 30.1 / 40.2 dB.  The gate
-        # proper is the DDPM chain above (the reference's default scheduler); here the bound only catches a
-        # regression beyond that amplification.
-        assert p_same >= 25.0 and p_tgt >= 33.0
+        # The 50-step DDIM chain (eta = 0.01: sigma_t ~ 1e-4, twenty-timestep jumps) amplifies every INCONSISTENT
+        # error of the denoiser (one that differs between the encoding and the regenerating evaluation of the same
+        # step, which the encoded noise therefore cannot cancel), and in bf16 nearly the whole rounding error is of
+        # that kind: a 1e-6 change of the input flips rounding decisions all through the network.
+        # test_ddim_bf16_end_image_follows_the_chains_own_amplification measures both and shows the fp32 oracle
+        # ending at 28.5 / 36.4 dB under independent noise of the bf16 size, against 30.1-32.1 / 39.2-40.2 dB
+        # measured here on different boxes: the 40 dB gate is NOT met for this chain, by the chain's own
+        # amplification, and the bound below only keeps the result within 2 dB of the lowest figure measured.
+        assert p_same >= 28.0 and p_tgt >= 37.0
 
 
 def test_ddim_bf16_end_image_follows_the_chains_own_amplification(dev):
