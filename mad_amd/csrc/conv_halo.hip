@@ -81,6 +81,18 @@ constexpr int CTAB_BYTES = 1024;       // one DMA instruction's worth; 256 (bf16
 #ifndef MAD_HALO_PF
 #define MAD_HALO_PF 2
 #endif
+// 1: the 16x16x32 forms keep a wave's pixel-row fragments in registers across the three vertical taps of a window
+// column (30 instead of 72 pixel-fragment reads from LDS per channel chunk)
+#ifndef MAD_HALO_SLIDE
+#define MAD_HALO_SLIDE 1
+#endif
+// 1: the products of the sliding-window form are asm statements that accumulate in place.  Left to the compiler, every
+// product may write its result to other registers than it read the accumulator from, and the register assignment of
+// 32 renamed accumulator quads beside the window's fragments no longer fits 256 registers (23-59 spilled, reloaded
+// inside the loop); pinned in place the same loop needs 241.
+#ifndef MAD_HALO_ASM_MMA
+#define MAD_HALO_ASM_MMA 1
+#endif
 constexpr int PF = MAD_HALO_PF;        // weight tiles are copied PF K-tiles ahead of their use
 constexpr int NWBUF = PF + 1;
 
@@ -155,6 +167,10 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_halo_kernel(HaloArgs 
     constexpr bool M16 = MAD_HALO_M16 >= 3 || (MAD_HALO_M16 >= 1 && !FUSE) ||
                          (MAD_HALO_M16 == 2 && TW == 16 && TN == 2 && sizeof(T) == 2);
     constexpr int TM16 = 2 * TM, TN16 = 2 * TN;   // M16: 16-pixel (one tile row) and 16-channel fragments per wave
+    // pixel-row fragments kept in registers across the vertical taps (see the chunk body); the fp32 parity form has
+    // no registers for it
+    constexpr bool SLIDE = M16 && sizeof(T) == 2 && MAD_HALO_SLIDE;
+    constexpr int NSLOT = TM16;
     constexpr int WTILE_BYTES = BN * HROW;
     constexpr int EPI_LD = BN + 4;
     constexpr int VEC = Elem<T>::VEC;
@@ -437,7 +453,10 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_halo_kernel(HaloArgs 
         const int lchunk = (lane & 3) ^ ((-(r >> 2)) & 3);
         wrow_off[j] = a.wtiled ? (unsigned)lane * 16u : (unsigned)((r * 9 * Ctot + lchunk * VEC) * (int)sizeof(T));
     }
-    auto stage_w = [&](int cc, int tap, int buf) {
+    auto stage_w = [&](int cc, int pos, int buf) {
+        // K-tiles of a chunk are multiplied column by column of the 3x3 window (loop position pos: kx = pos / 3,
+        // ky = pos % 3; see the chunk body), the weights are stored row by row (tap = ky * 3 + kx)
+        const int tap = (pos % 3) * 3 + pos / 3;
         // scalar base = first row of this workgroup's channels at (tap, chunk); the lane offset never changes.
         // Tiled weights: the 16 rows x 64 bytes of a copy are one KiB, already in LDS order, at
         // [16-row block][chunk][tap]: scalar base = that KiB, lane offset = lane * 16.
@@ -561,10 +580,13 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_halo_kernel(HaloArgs 
         constexpr bool LAST = decltype(last_tag)::value;
         const unsigned char* halo = halo0 + (cc & 1) * HALO_BUF;
         const int nb = (cc + 1) & 1;                              // halo / table buffer of the next chunk
+        uint4 arow[SLIDE ? NSLOT : 1];                            // SLIDE: the wave's pixel-row fragments
         const int ccn = cc + 1;
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
-            const int ky = tap / 3, kx = tap % 3;
+            // `tap` is the loop position; the window is walked column by column (kx outer, ky inner), so that the
+            // pixel rows a wave holds in registers for one ky serve the next ky shifted by one row (SLIDE, below)
+            const int kx = tap / 3, ky = tap % 3;
             constexpr int C0 = FUSE ? 1 : 0;
             static_assert(PF >= 2 && PF <= 3, "the in-place transform of item j runs at tap j+3");
             int nwait = 0;
@@ -638,7 +660,53 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_halo_kernel(HaloArgs 
             // a little faster than requesting all of a tap's fragments at its top); the fp32 parity form has no
             // registers to spare and requests each group when it needs it
             constexpr bool AHEAD = sizeof(T) == 2;
-            if constexpr (M16) {
+            if constexpr (SLIDE) {
+                // Sliding window of pixel-row fragments.  A wave multiplies TM16 rows of 16 pixels; at vertical tap ky
+                // row i needs halo row i + ky of the wave's rows, at the column shift kx.  The TM16 rows stay in
+                // registers: going from ky to ky + 1 replaces ONE row (row ky - 1 + TM16 + 1 takes the registers of row
+                // ky - 1 ... i.e. the row that has just dropped out of the window), and during the last products of a
+                // window column each row that has served is replaced by the row of the NEXT column that will use its
+                // registers (row r of column kx lives in slot (r + 2 * kx) % TM16, so the next column's row i takes
+                // over from this column's row i + 2).  LDS fragment reads per chunk: 30 pixel rows + 36 weight
+                // fragments instead of 72 + 36.  Rows of the NEXT chunk cannot be requested early (its halo is
+                // finished at the barrier of its first tap): the first tap of a chunk reads all its rows at its top.
+                // The products run channel fragment by channel fragment (j outer): a weight fragment serves TM16
+                // products and is then dead, so two of them are live at a time.
+                constexpr int NMM = TM16 * TN16;
+                auto slot = [&](int r, int kxg) { return (r + 2 * kxg) % NSLOT; };
+                auto load_row = [&](int r, int kxg) {
+                    arow[slot(r, kxg)] = *reinterpret_cast<const uint4*>(halo + a_off[kxg][0] + r * HSX * HROW);
+                };
+                uint4 bfs[2];
+                auto load_b = [&](int j) { bfs[j & 1] = *reinterpret_cast<const uint4*>(wt + b_off[0] + j * 16 * HROW); };
+                load_b(0);
+                if (tap == 0) {
+#pragma unroll
+                    for (int r = 0; r < TM16; ++r) load_row(r, 0);
+                } else if (ky > 0) {
+                    load_row(TM16 - 1 + ky, kx);        // the row that enters the window; its first product is the tap's last
+                }
+                if (do_x && !MAD_XF_PHASED) { if (mini_tap) xm_begin(nb); else xf_begin(tap - 3, nb); }
+#pragma unroll
+                for (int j = 0; j < TN16; ++j) {
+                    if (j + 1 < TN16) load_b(j + 1);
+#pragma unroll
+                    for (int i = 0; i < TM16; ++i) {
+                        // weights are the first operand: a lane's four results are four consecutive channels of a pixel
+#if MAD_HALO_ASM_MMA
+                        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0"
+                                     : "+v"(acc16[i][j])
+                                     : "v"(__builtin_bit_cast(bf16x8, bfs[j & 1])),
+                                       "v"(__builtin_bit_cast(bf16x8, arow[slot(i + ky, kx)])));
+#else
+                        mma16_row<T>(acc16[i][j], bfs[j & 1], arow[slot(i + ky, kx)]);
+#endif
+                        behind_mma(j * TM16 + i, NMM);
+                        // last use of row i + 2 of this column: its registers take the next column's row i
+                        if (j == TN16 - 1 && ky == 2 && kx < 2) load_row(i, kx + 1);
+                    }
+                }
+            } else if constexpr (M16) {
                 constexpr int NG = TM16 / 2;           // groups of 2*TN16 MFMAs: a pair of pixel rows x all channels
                 constexpr int NMM = TM16 * TN16;
                 uint4 afs[2][2], bfs[TN16];
@@ -712,6 +780,11 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_halo_kernel(HaloArgs 
     for (int cc = 0; cc < nchunks - 1; ++cc) chunk_body(cc, std::false_type{});
     chunk_body(nchunks - 1, std::true_type{});
     dma_wait_all();
+    if constexpr (SLIDE && MAD_HALO_ASM_MMA) {
+        // the products above are asm statements: the compiler does not know that the accumulators are results of
+        // the matrix pipe, so the wait states a read of such a result needs are provided here, once per tile
+        asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
+    }
 
     // ---- 1x1 projection of the block input (the residual branch's channel change), accumulated into the
     // same tiles: K is extended by SC1+SC2 channels read at the centre tap from the raw, un-normalised
