@@ -86,6 +86,12 @@ constexpr int CTAB_BYTES = 1024;       // one DMA instruction's worth; 256 (bf16
 #ifndef MAD_HALO_SLIDE
 #define MAD_HALO_SLIDE 1
 #endif
+// 1: the bf16 16x16x32 forms write their output straight from the accumulators (lane pairs exchange four-channel quads
+// with v_permlane16_swap so that every lane holds eight consecutive channels of its pixel): no LDS hand-over, no
+// barriers between the products and the stores, statistics reduced across pixel columns by DPP
+#ifndef MAD_HALO_DSE
+#define MAD_HALO_DSE 1
+#endif
 // 1: the products of the sliding-window form are asm statements that accumulate in place.  Left to the compiler, every
 // product may write its result to other registers than it read the accumulator from, and the register assignment of
 // 32 renamed accumulator quads beside the window's fragments no longer fits 256 registers (23-59 spilled, reloaded
@@ -101,6 +107,11 @@ constexpr int NWBUF = PF + 1;
 // second channel chunk, [wave][tap][point]; points: tap top, copies landed, barrier passed,
 // MFMAs issued, transform done.
 __device__ unsigned g_stamps[8 * 9 * 8];
+// Clock aid of the same build: every workgroup leaves (shader cycles, 100 MHz reference ticks) between its first and
+// its last instruction; cycles / ticks * 100 MHz is the clock the chip held while the workgroup ran.  The values go to
+// this array only, which nothing else in the kernel reads.
+constexpr int CLOCK_SLOTS = 8192;
+__device__ unsigned long long g_clock[CLOCK_SLOTS * 2];
 #define MAD_STAMP(pt)                                                                      \
     if (stamp_on && cc == 1) {                                                             \
         const unsigned t_ = (unsigned)__builtin_readcyclecounter();                        \
@@ -171,6 +182,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_halo_kernel(HaloArgs 
     // no registers for it
     constexpr bool SLIDE = M16 && sizeof(T) == 2 && MAD_HALO_SLIDE;
     constexpr int NSLOT = TM16;
+    constexpr bool DSE = M16 && sizeof(T) == 2 && !OUT_NCHW && !GSTAT && MAD_HALO_DSE;
     constexpr int WTILE_BYTES = BN * HROW;
     constexpr int EPI_LD = BN + 4;
     constexpr int VEC = Elem<T>::VEC;
@@ -217,6 +229,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_halo_kernel(HaloArgs 
         }
     }
 #ifdef MAD_HALO_STAMPS
+    const unsigned long long clk_c0 = __builtin_readcyclecounter(), clk_r0 = __builtin_amdgcn_s_memrealtime();
     unsigned* const stamp_lds = reinterpret_cast<unsigned*>(smem + halo_lds_bytes<BN, TW>() - 4096);
     const bool stamp_on = blockIdx.x == gridDim.x / 2 + 3;
     const int lane_ = threadIdx.x & 63, wave_ = threadIdx.x >> 6;
@@ -906,6 +919,138 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_halo_kernel(HaloArgs 
             }
         }
         return;
+    } else if constexpr (DSE) {
+        // ---- epilogue straight from the accumulators.  Lane (fr, fh) of a wave holds, for pixel column fr of each
+        // of its TM16 rows and each 16-channel block j, the four channels 16*j + 4*fh .. +3.  v_permlane16_swap
+        // exchanges, between the lanes fh and fh ^ 1 of a pixel, the quad of block 2p+1 against the quad of block 2p:
+        // afterwards an even fh holds channels 4*fh .. 4*fh+7 of block 2p and an odd fh channels 4*(fh-1) .. +7 of
+        // block 2p+1 -- eight consecutive channels, one 16-byte store, and the four lanes of a pixel cover 64
+        // contiguous bytes.  Residual rows are requested a row group ahead.  Statistics: per lane over its rows (pair
+        // sums by v_dot2c_f32_bf16 on the packed output), then over the 16 pixel columns by a DPP butterfly, then over
+        // the waves that share channels through LDS in wave order: a fixed order, so results are deterministic.
+        constexpr int NP = TN16 / 2;                    // pairs of 16-channel blocks per wave
+        const T* res = (const T*)a.residual;
+        T* y = (T*)a.y;
+        const int cb0 = wn * (TN * 32) + (fh & 1) * 16 + (fh >> 1) * 8;     // this lane's first channel, pair 0
+        float ssum[NP][4], ssq[NP][4];
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { ssum[p][k] = 0.0f; ssq[p][k] = 0.0f; }
+        const int half = (wm * WAVE_PIX) >> 8;          // 16-column half of a 32-wide tile this wave's rows lie in
+        const int ox = tx0 + half * 16 + fr;
+        const bool has_res = a.res_mode == MAD_RES_SAME || a.res_mode == MAD_RES_UP;
+        constexpr int RG = 4;                           // rows per group of residual requests
+        static_assert(TM16 % RG == 0, "whole row groups");
+        auto row_y = [&](int i) { return ty0 + (((wm * WAVE_PIX) >> 4) & 15) + i; };
+#pragma unroll
+        for (int i0 = 0; i0 < TM16; i0 += RG) {
+            uint4 rpre[RG][NP];
+            if (has_res) {
+#pragma unroll
+                for (int r = 0; r < RG; ++r) {
+                    const int oy = row_y(i0 + r);
+                    const size_t rp = a.res_mode == MAD_RES_SAME
+                                          ? ((size_t)b * a.H + oy) * a.W + ox
+                                          : ((size_t)b * (a.H >> 1) + (oy >> 1)) * (a.W >> 1) + (ox >> 1);
+#pragma unroll
+                    for (int p = 0; p < NP; ++p)
+                        rpre[r][p] = *reinterpret_cast<const uint4*>(res + rp * a.Cout + n0 + cb0 + p * 32);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < RG; ++r) {
+                const int i = i0 + r;
+                const int oy = row_y(i);
+                const size_t m = ((size_t)b * a.H + oy) * a.W + ox;
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc16[i][2 * p][e]),
+                                                                         __float_as_uint(acc16[i][2 * p + 1][e]), false, false);
+                        v[e] = __uint_as_float(sw[0]); v[4 + e] = __uint_as_float(sw[1]);
+                    }
+                    if (has_res) {
+                        Vec16<T> rv; rv.raw = rpre[r][p];
+                        float f[8]; rv.unpack(f);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] += f[e];
+                    } else if (a.res_mode == MAD_RES_DOWN) {
+                        float sd[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) sd[e] = 0.0f;
+#pragma unroll
+                        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                            for (int dx = 0; dx < 2; ++dx) {
+                                const size_t rp = ((size_t)b * (2 * a.H) + (2 * oy + dy)) * (2 * a.W) + (2 * ox + dx);
+                                Vec16<T> rv; rv.load(res + rp * a.Cout + n0 + cb0 + p * 32);
+                                float f[8]; rv.unpack(f);
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) sd[e] += f[e];
+                            }
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = fmaf(sd[e], 0.25f, v[e]);
+                    }
+                    Vec16<T> o; o.pack(v);
+                    T* dst = y + m * a.Cout + n0 + cb0 + p * 32;
+                    if (a.stream_out) o.store_nt(dst); else o.store(dst);
+                    if (a.stats) {
+                        const unsigned* w4 = reinterpret_cast<const unsigned*>(&o.raw);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(ssum[p][k]) : "v"(w4[k]), "v"(0x3f803f80u));
+                            asm("v_dot2c_f32_bf16 %0, %1, %1" : "+v"(ssq[p][k]) : "v"(w4[k]));
+                        }
+                    }
+                }
+            }
+        }
+        if (a.stats) {
+            // over the 16 pixel columns: lanes ^1, ^2 inside a quad, then the mirrored quad, then the mirrored half row
+            auto row16_sum = [](float x) {
+                x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, true));
+                x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xF, 0xF, true));
+                x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x141, 0xF, 0xF, true));
+                x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x140, 0xF, 0xF, true));
+                return x;
+            };
+#pragma unroll
+            for (int p = 0; p < NP; ++p)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { ssum[p][k] = row16_sum(ssum[p][k]); ssq[p][k] = row16_sum(ssq[p][k]); }
+            __syncthreads();                              // every wave is done with the staging buffers
+            float* red = reinterpret_cast<float*>(smem);  // [WM][BN / 2 channel pairs][2]
+            if (fr == 0) {
+#pragma unroll
+                for (int p = 0; p < NP; ++p)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int pr = (cb0 + p * 32) / 2 + k;
+                        red[(wm * (BN / 2) + pr) * 2] = ssum[p][k];
+                        red[(wm * (BN / 2) + pr) * 2 + 1] = ssq[p][k];
+                    }
+            }
+            __syncthreads();
+            if (tid < BN / 2) {
+                float sm = 0.0f, sq = 0.0f;
+#pragma unroll
+                for (int w = 0; w < WM; ++w) { sm += red[(w * (BN / 2) + tid) * 2]; sq += red[(w * (BN / 2) + tid) * 2 + 1]; }
+                // one row of sums per 16x16 tile of the image, per channel pair: (sum, sum of squares) in the slot of the
+                // even channel, zeros in the slot of the odd one; a 32-wide tile writes its sums to the row of its left
+                // half and zeros to the row of its right half (the consumer adds the rows up)
+                const int tile16 = (tile / a.tiles_x) * (a.W / 16) + (tile % a.tiles_x) * (TW / 16);
+                const size_t tiles16_img = (size_t)(a.H / 16) * (a.W / 16);
+                float4* srow = reinterpret_cast<float4*>(a.stats + ((b * tiles16_img + tile16) * a.Cout + n0) * 2);
+                srow[tid] = make_float4(sm, sq, 0.0f, 0.0f);
+                if (TW == 32) {
+                    float4* srow1 = reinterpret_cast<float4*>(a.stats + ((b * tiles16_img + tile16 + 1) * a.Cout + n0) * 2);
+                    srow1[tid] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                }
+            }
+        }
     } else {
     constexpr int CPR = BN / VEC;            // 16-byte chunks per output row
     constexpr int RPP = NT / CPR;            // rows per pass
@@ -1073,6 +1218,11 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_halo_kernel(HaloArgs 
     MAD_STAMP_PHASE(2 + 7)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     MAD_STAMP_PHASE(2 + 8)
+    if (threadIdx.x == 0) {
+        const unsigned long long c1 = __builtin_readcyclecounter(), r1 = __builtin_amdgcn_s_memrealtime();
+        g_clock[(blockIdx.x % CLOCK_SLOTS) * 2] = c1 - clk_c0;
+        g_clock[(blockIdx.x % CLOCK_SLOTS) * 2 + 1] = r1 - clk_r0;
+    }
     if (stamp_on) {
         __syncthreads();
         for (int i = tid; i < NWAVES * 9 * 8; i += NT) g_stamps[i] = stamp_lds[i];
@@ -1255,6 +1405,10 @@ extern "C" int mad_conv3x3_gn_bwd_sums(const void* x, int Cin, const void* w, vo
 #ifdef MAD_HALO_STAMPS
 extern "C" int mad_debug_read_stamps(unsigned* out) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned) * 8 * 9 * 8) == hipSuccess ? 0 : 1;
+}
+// (cycles, reference ticks) of the workgroups of the last launches: `n` pairs, n <= 8192
+extern "C" int mad_debug_read_clock(unsigned long long* out, int n) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_clock), sizeof(unsigned long long) * 2 * (size_t)n) == hipSuccess ? 0 : 1;
 }
 #endif
 
