@@ -226,28 +226,6 @@ int mad_conv3x3_fused_skip(const void* x1, int C1, const void* x2, int C2, const
                            int SC2, const void* sw, void* y, float* stats, int dtype, int B, int H, int W,
                            int Cout, void* stream);
 
-/* mad_conv3x3_fused / mad_conv3x3_fused_skip (SC1 = 0: no projection) that also FINISHES the GroupNorm its output
- * feeds: coef (B, Cout + C2, 2) as mad_gn_finalize_scaled would write it from `stats` (nsplit = (H/16)*(W/16)) and
- * an optional second slab of C2 further channels (a skip tensor the consumer concatenates).  Where the launch writes
- * its output straight from the accumulators (bf16) the workgroup that stores a sample's last row of sums does it --
- * one arrival counter per sample, `counters` (B zero-initialised uint32, left zero), agent-scope release / acquire
- * around it -- otherwise the stand-alone kernel runs behind the launch: the same values to the last bit either way
- * (MAD_GN_FOLD=0 in the environment forces the stand-alone kernel).  `stats` must be given.
- * Replaces Conv2d followed by the statistics + affine folding of the next GroupNorm (model.py:339-350, 182-190). */
-typedef struct mad_gn_fin {
-    const float* partial2; int C2; int nsplit2;   /* second slab (B, nsplit2, C2, 2), or NULL / 0 / 0 */
-    const float* gamma; const float* beta;         /* gain / offset over Cout + C2 channels */
-    const float* ada; int ada_stride;              /* AdaGN rows as in mad_gn_finalize, or NULL */
-    float* coef;                                   /* out (B, Cout + C2, 2) */
-    int groups; int HW; float eps; float scale;    /* as in mad_gn_finalize_scaled */
-    unsigned int* counters;                        /* B arrival counters, zero between calls */
-} mad_gn_fin;
-int mad_conv3x3_fused_gn(const void* x1, int C1, const void* x2, int C2, const float* coef, int act,
-                         const void* w, const float* bias, const void* residual, int res_mode,
-                         const void* sx1, int SC1, const void* sx2, int SC2, const void* sw, void* y,
-                         float* stats, const mad_gn_fin* fin, int dtype, int B, int H, int W, int Cout,
-                         int upsample, void* stream);
-
 /* The same GroupNorm -> SiLU -> Conv2d(3x3) -> (+ residual) -> statistics fusion for the 8x8 layers
  * (H = W = 8 is implied): one workgroup holds a whole image's input in LDS.  x is the concatenation of
  * x1 (C1) and x2 (C2), NHWC (B,8,8,C); C1, C2 multiples of 64 (bf16) / 32 (fp32); Cout a multiple of 64.

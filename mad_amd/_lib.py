@@ -34,13 +34,6 @@ class SamplerCoef(Structure):
                 ("dir_coef", c_float), ("clip_range", c_float), ("eps_div", c_float)]
 
 
-class GnFin(Structure):
-    """Mirror of ``mad_gn_fin``: the GroupNorm a conv launch finishes (see ``mad_conv3x3_fused_gn``)."""
-    _fields_ = [("partial2", c_void_p), ("C2", c_int), ("nsplit2", c_int), ("gamma", c_void_p), ("beta", c_void_p),
-                ("ada", c_void_p), ("ada_stride", c_int), ("coef", c_void_p), ("groups", c_int), ("HW", c_int),
-                ("eps", c_float), ("scale", c_float), ("counters", c_void_p)]
-
-
 # name -> (restype, argtypes); must list every function include/mad_hip.h declares
 SIGNATURES = {
     "mad_version": (c_int, []),
@@ -72,9 +65,6 @@ SIGNATURES = {
     "mad_conv3x3_fused_skip": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p,
                                        c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p] + [c_int] * 5 +
                                [c_void_p]),
-    "mad_conv3x3_fused_gn": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
-                                     c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
-                                     POINTER(GnFin)] + [c_int] * 6 + [c_void_p]),
     "mad_conv3x3_img8": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int,
                                  c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "mad_conv_wgrad_workspace": (ctypes.c_size_t, [c_int] * 7),

@@ -23,7 +23,6 @@
 //            fixed order (deterministic).  fp32: per channel.  bf16: per channel PAIR (2i, 2i+1), both sums in
 //            slot 2i and zeros in slot 2i+1 -- a GroupNorm group holds whole pairs and only group sums are used.
 #include "mma.h"
-#include "gn_fin.h"
 #include <cstdlib>
 #include <type_traits>
 
@@ -46,9 +45,6 @@ struct HaloArgs {
     const void* gx1; const void* gx2; const float* gcoef;
     int gC1, gact;
     DropMask gdm;
-    // The GroupNorm that consumes this layer's statistics, finished in this launch by the workgroup that stores a
-    // sample's last row of sums (fin.coef null: not asked for; only the direct-store epilogue does it)
-    GnFin fin;
 };
 
 constexpr int HT = 16;                 // output tile height (and width of the narrow tile)
@@ -1054,12 +1050,6 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_halo_kernel(HaloArgs 
                     srow1[tid] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                 }
             }
-            if (a.fin.coef) {
-                // the workgroup that stores the sample's last row of sums turns them into the (a, d) pairs of the
-                // GroupNorm that follows: no launch of its own for that
-                unsigned* flag = reinterpret_cast<unsigned*>(smem + 4096);
-                if (gn_fin_arrive(a.fin, b, tid, flag)) gn_fin_tail<NT>(a.fin, b, tid, reinterpret_cast<double*>(smem + 8192));
-            }
         }
     } else {
     constexpr int CPR = BN / VEC;            // 16-byte chunks per output row
@@ -1268,7 +1258,7 @@ static int conv3x3_fused_impl(const void* x1, int C1, const void* x2, int C2, co
                               const void* w, const float* bias, const void* residual, int res_mode, void* y,
                               float* stats, int dtype, int B, int H, int W, int Cout, int upsample,
                               const void* sx1, int SC1, const void* sx2, int SC2, const void* sw, void* stream,
-                              const GnFold* gn = nullptr, const mad_gn_fin* fin = nullptr) {
+                              const GnFold* gn = nullptr) {
     MAD_REQUIRE(x1 && w && y, "mad_conv3x3_fused: null pointer");
     MAD_REQUIRE(dtype == MAD_BF16 || dtype == MAD_F32, "mad_conv3x3_fused: bad dtype %d", dtype);
     const int CK = dtype == MAD_BF16 ? 32 : 16;
@@ -1339,41 +1329,6 @@ static int conv3x3_fused_impl(const void* x1, int C1, const void* x2, int C2, co
     bool bn256 = bn256_fits && B * a.tiles_x * a.tiles_y * (Cout / 256) >= 256;
     if (const char* f = getenv("MAD_HALO_BN256"))            // tuning / test aid: 0 = never, 2 = wherever it fits
         bn256 = atoi(f) == 2 ? bn256_fits : (bn256 && atoi(f) != 0);
-    // The GroupNorm that follows, finished inside the launch(es) when every one of them writes its output straight
-    // from the accumulators (bf16; without the loader transform every form does, with it the 128- / 256-channel
-    // workgroups on 16x16 tiles); by the stand-alone kernel behind them otherwise.  Same numbers either way.
-    a.fin.coef = nullptr;
-    bool fold = false;
-    const int tiles16 = (H / 16) * (W / 16);
-    if (fin) {
-        MAD_REQUIRE(stats && fin->gamma && fin->beta && fin->coef && fin->counters,
-                    "mad_conv3x3_fused_gn: the finalize needs stats, gamma, beta, coef and the arrival counters");
-        MAD_REQUIRE(fin->C2 >= 0 && (fin->C2 == 0 || (fin->partial2 && fin->nsplit2 > 0)) && fin->groups > 0 &&
-                        (Cout + fin->C2) % fin->groups == 0 && fin->HW > 0,
-                    "mad_conv3x3_fused_gn: bad finalize description (C2=%d nsplit2=%d groups=%d HW=%d)", fin->C2,
-                    fin->nsplit2, fin->groups, fin->HW);
-        const char* off = getenv("MAD_GN_FOLD");
-        fold = dtype == MAD_BF16 && !gn && (!coef || (mode == 128 && !wide_ok)) && !(off && atoi(off) == 0);
-        if (fold) {
-            const int tiles_w = (wide_ok ? W / 32 : W / 16) * (H / 16);
-            int arrivals;
-            if (mode == 128) arrivals = (bn256 ? Cout / 256 : Cout / 128) * tiles_w;
-            else if (mode == 64) arrivals = (Cout / 64) * tiles16;
-            else arrivals = (Cout / 128) * tiles_w + tiles16;
-            GnFin& f = a.fin;
-            f.partial1 = stats; f.C1 = Cout; f.ns1 = tiles16;
-            f.partial2 = fin->C2 ? fin->partial2 : stats; f.C2 = fin->C2; f.ns2 = fin->C2 ? fin->nsplit2 : 1;
-            f.gamma = fin->gamma; f.beta = fin->beta; f.ada = fin->ada; f.ada_stride = fin->ada_stride;
-            f.coef = fin->coef; f.groups = fin->groups; f.HW = fin->HW; f.eps = fin->eps; f.scale = fin->scale;
-            f.counters = fin->counters; f.arrivals = arrivals;
-        }
-    }
-    auto finish = [&](int rc) -> int {
-        if (rc || !fin || fold) return rc;
-        return mad_gn_finalize_scaled(stats, Cout, tiles16, fin->partial2, fin->C2, fin->nsplit2, fin->gamma, fin->beta,
-                                      fin->ada, fin->ada_stride, fin->coef, B, fin->groups, fin->HW, fin->eps,
-                                      fin->scale, stream);
-    };
     auto run = [&](bool narrow) -> int {
         if (wide_ok && !narrow) {
             if (SC1 > 0)
@@ -1411,22 +1366,10 @@ static int conv3x3_fused_impl(const void* x1, int C1, const void* x2, int C2, co
         a.ntiles_n = Cout / 128;
         if (int rc = run(false)) return rc;
         a.n_off = Cout - 64; a.ntiles_n = 1;
-        return finish(run(true));
+        return run(true);
     }
     a.ntiles_n = bn256 ? Cout / 256 : Cout / mode;
-    return finish(run(mode == 64));
-}
-
-extern "C" int mad_conv3x3_fused_gn(const void* x1, int C1, const void* x2, int C2, const float* coef, int act,
-                                    const void* w, const float* bias, const void* residual, int res_mode,
-                                    const void* sx1, int SC1, const void* sx2, int SC2, const void* sw, void* y,
-                                    float* stats, const mad_gn_fin* fin, int dtype, int B, int H, int W, int Cout,
-                                    int upsample, void* stream) {
-    MAD_REQUIRE(fin, "mad_conv3x3_fused_gn: null finalize description");
-    MAD_REQUIRE(SC1 == 0 || (res_mode == MAD_RES_NONE && !upsample),
-                "mad_conv3x3_fused_gn: the fused projection excludes a residual tensor and upsampling");
-    return conv3x3_fused_impl(x1, C1, x2, C2, coef, act, w, bias, residual, res_mode, y, stats, dtype, B, H, W, Cout,
-                              upsample, sx1, SC1, sx2, SC2, sw, stream, nullptr, fin);
+    return run(mode == 64);
 }
 
 extern "C" int mad_conv3x3_fused(const void* x1, int C1, const void* x2, int C2, const float* coef, int act,
@@ -1487,7 +1430,6 @@ extern "C" int mad_conv_out_fused(const void* x, int Cin, const float* coef, int
     a.C1 = Cin; a.C2 = 0; a.B = B; a.H = H; a.W = W; a.Cout = Cout; a.upsample = 0; a.res_mode = MAD_RES_NONE;
     a.act = act; a.Hs = H; a.Ws = W;
     a.sx1 = a.sx2 = a.sw = nullptr; a.SC1 = a.SC2 = 0; a.stream_out = 0; a.wtiled = 0;
-    a.fin.coef = nullptr;
     a.tiles_x = W / HT; a.tiles_y = H / HT; a.ntiles_n = 1; a.n_off = 0;
     hipStream_t s = (hipStream_t)stream;
     const char* what = "mad_conv_out_fused";

@@ -3,7 +3,6 @@
 // apply pass y = act(x*a + d) that can also average 2x2 pixels (the encoder's downsample).
 // All of it is HBM-bound: 16-byte vector accesses, wave-level reductions, fp32 statistics.
 #include "common.h"
-#include "gn_fin.h"
 #include <algorithm>
 
 #include <mutex>
@@ -80,13 +79,40 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const T* __restrict__ x
 // partial-sum slabs (C1 channels in nsplit1 splits, C2 channels in nsplit2 splits).  Partials are
 // combined in fp64 in a fixed order, then the lanes write the per-channel (a, d) pairs.
 template <int NWV>
-__global__ __launch_bounds__(64 * NWV) void gn_finalize_kernel(GnFin f) {
+__global__ __launch_bounds__(64 * NWV) void gn_finalize_kernel(const float* __restrict__ partial1, int C1, int nsplit1,
+                                                          const float* __restrict__ partial2, int C2, int nsplit2,
+                                                          const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta,
+                                                          const float* __restrict__ ada, int ada_stride,
+                                                          float* __restrict__ coef, int groups, int HW, float eps,
+                                                          float out_scale) {
     constexpr int NT = 64 * NWV;
     const int g = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;       // lane: index in the workgroup
-    const int gs[1] = {g};
-    double s, q;
-    gn_lane_sums<NT, 1>(f, b, gs, lane, &s, &q);
-    gn_wave_sums<1>(&s, &q);
+    const int C = C1 + C2, cpg = C / groups;
+    const int max_ns = nsplit1 > nsplit2 ? nsplit1 : nsplit2;
+    double s = 0.0, q = 0.0;
+    // four independent loads in flight per lane (the sums are accumulated in the order of a one-at-a-time loop)
+    const int total = cpg * max_ns;
+    for (int it0 = lane; it0 < total; it0 += 4 * NT) {
+        float2 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int it = it0 + NT * u;
+            const int itc = it < total ? it : 0;
+            const int c = g * cpg + itc / max_ns, sp = itc % max_ns;
+            const bool first = c < C1;
+            const int ns = first ? nsplit1 : nsplit2;
+            const int spc = sp < ns ? sp : ns - 1;
+            const float* p = first ? partial1 + (((size_t)b * nsplit1 + spc) * C1 + c) * 2
+                                   : partial2 + (((size_t)b * nsplit2 + spc) * C2 + (c - C1)) * 2;
+            v[u] = *reinterpret_cast<const float2*>(p);
+            if (it >= total || sp >= ns) v[u] = make_float2(0.0f, 0.0f);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { s += (double)v[u].x; q += (double)v[u].y; }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { s += __shfl_xor(s, off); q += __shfl_xor(q, off); }
     if (NWV > 1) {
         __shared__ double wsum[NWV][2];
         if ((lane & 63) == 0) { wsum[lane >> 6][0] = s; wsum[lane >> 6][1] = q; }
@@ -95,7 +121,25 @@ __global__ __launch_bounds__(64 * NWV) void gn_finalize_kernel(GnFin f) {
 #pragma unroll
         for (int w = 0; w < NWV; ++w) { s += wsum[w][0]; q += wsum[w][1]; }
     }
-    gn_write_coef<NT>(f, b, g, lane, s, q);
+    const double n = (double)HW * cpg;
+    const double mean = s / n;
+    double var = q / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float mean_f = (float)mean, rstd_f = (float)(1.0 / sqrt(var + (double)eps));
+    for (int i = lane; i < cpg; i += NT) {
+        const int c = g * cpg + i;
+        const float rg = rstd_f * gamma[c];
+        float a = rg;
+        float d = beta[c] - mean_f * rg;
+        if (ada) {
+            const float sc = ada[(size_t)b * ada_stride + c] + 1.0f;
+            const float sh = ada[(size_t)b * ada_stride + C + c];
+            a = a * sc;
+            d = fmaf(d, sc, sh);
+        }
+        coef[((size_t)b * C + c) * 2] = a * out_scale;
+        coef[((size_t)b * C + c) * 2 + 1] = d * out_scale;
+    }
 }
 
 // ------------------------------------------------------------------------------- apply
@@ -218,15 +262,15 @@ extern "C" int mad_gn_finalize_scaled(const float* partial1, int C1, int nsplit1
                 "mad_gn_finalize: bad partial-sum layout C1=%d nsplit1=%d C2=%d nsplit2=%d", C1, nsplit1, C2, nsplit2);
     MAD_REQUIRE(B > 0 && groups > 0 && (C1 + C2) % groups == 0, "mad_gn_finalize: bad C=%d groups=%d", C1 + C2, groups);
     MAD_REQUIRE(HW > 0, "mad_gn_finalize: bad HW");
-    GnFin f;
-    f.partial1 = partial1; f.C1 = C1; f.ns1 = nsplit1;
-    f.partial2 = C2 ? partial2 : partial1; f.C2 = C2; f.ns2 = C2 ? nsplit2 : 1;
-    f.gamma = gamma; f.beta = beta; f.ada = ada; f.ada_stride = ada_stride; f.coef = coef;
-    f.groups = groups; f.HW = HW; f.eps = eps; f.scale = scale; f.counters = nullptr; f.arrivals = 0;
-    if (gn_wide_team((C1 + C2) / groups, std::max(f.ns1, f.ns2)))
-        hipLaunchKernelGGL(gn_finalize_kernel<4>, dim3(groups, B), dim3(256), 0, (hipStream_t)stream, f);
+    const int longest = ((C1 + C2) / groups) * std::max(nsplit1, C2 ? nsplit2 : 1);     // pairs per group
+    if (longest >= 512)
+        hipLaunchKernelGGL(gn_finalize_kernel<4>, dim3(groups, B), dim3(256), 0, (hipStream_t)stream, partial1, C1,
+                           nsplit1, C2 ? partial2 : partial1, C2, C2 ? nsplit2 : 1, gamma, beta, ada, ada_stride, coef,
+                           groups, HW, eps, scale);
     else
-        hipLaunchKernelGGL(gn_finalize_kernel<1>, dim3(groups, B), dim3(64), 0, (hipStream_t)stream, f);
+        hipLaunchKernelGGL(gn_finalize_kernel<1>, dim3(groups, B), dim3(64), 0, (hipStream_t)stream, partial1, C1,
+                           nsplit1, C2 ? partial2 : partial1, C2, C2 ? nsplit2 : 1, gamma, beta, ada, ada_stride, coef,
+                           groups, HW, eps, scale);
     return check_launch("mad_gn_finalize");
 }
 

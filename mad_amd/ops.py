@@ -311,31 +311,16 @@ def halo_tile_weights(w: Tensor, dtype: torch.dtype, scale: float = 1.0) -> Tens
     return torch.gather(w6, 4, idx).contiguous()
 
 
-_FIN_COUNTERS: dict = {}
-
-
-def _fin_counters(device, B: int) -> Tensor:
-    """The arrival counters of the in-launch GroupNorm finalize: one zero-initialised int32 per sample and device,
-    shared by every launch on the device (launches on a stream follow one another; each leaves the counters at zero)."""
-    t = _FIN_COUNTERS.get(device)
-    if t is None or t.numel() < B:
-        t = _FIN_COUNTERS[device] = torch.zeros(max(B, 256), dtype=torch.int32, device=device)
-    return t
-
-
 def conv3x3_fused(x1: Tensor, w: Tensor, bias: Optional[Tensor], coef: Optional[Tensor] = None, act: bool = True,
                   x2: Optional[Tensor] = None, residual: Optional[Tensor] = None, res_mode: int = _lib.RES_NONE,
                   upsample: bool = False, want_stats: bool = False, skip: Optional[tuple] = None,
-                  prescaled: bool = False, w_tiled: bool = False, fin: Optional[dict] = None):
+                  prescaled: bool = False, w_tiled: bool = False):
     """Halo-tile 3x3 conv with the input's GroupNorm(+SiLU) applied in the loader (coef (B,C,2) or None)
     and, optionally, per-tile statistics of the output (B, tiles, Cout, 2) for the next GroupNorm.
     ``skip=(s1, s2_or_None, sw)`` adds the 1x1 projection ``sw (Cout, SC1+SC2)`` of the raw concatenation
     [s1, s2] in the same launch (``bias`` must then already hold the sum of both layers' biases).
     ``prescaled``: coef comes from ``gn_finalize(..., scale=_lib.PRESCALE_COEF)`` and w carries ``_lib.PRESCALE_W``;
-    ``w_tiled``: w is the result of ``halo_tile_weights``.
-    ``fin``: the GroupNorm the output feeds, finished by the same call -- dict(gamma, beta, groups, eps, and optionally
-    ada, ada_stride, partial2 (statistics of further channels the consumer concatenates), scale); the call then returns
-    (y, stats, coef) with coef (B, Cout + C2, 2) equal to ``gn_finalize(stats, H*W, ...)`` bit for bit."""
+    ``w_tiled``: w is the result of ``halo_tile_weights``."""
     _dev(x1, x2, w, bias, coef, residual)
     B, Hs, Ws, C1 = x1.shape
     C2 = 0 if x2 is None else x2.shape[3]
@@ -363,9 +348,6 @@ def conv3x3_fused(x1: Tensor, w: Tensor, bias: Optional[Tensor], coef: Optional[
         raise ValueError("res_mode set without a residual tensor")
     y = torch.empty((B, H, W_, Cout), dtype=x1.dtype, device=x1.device)
     stats = torch.empty((B, (H // 16) * (W_ // 16), Cout, 2), dtype=torch.float32, device=x1.device) if want_stats else None
-    s1 = s2 = sw = None
-    SC1 = SC2 = 0
-    flops = 2.0 * B * H * W_ * Cout * (C1 + C2) * 9
     if skip is not None:
         s1, s2, sw = skip
         _dev(s1, s2, sw)
@@ -375,41 +357,17 @@ def conv3x3_fused(x1: Tensor, w: Tensor, bias: Optional[Tensor], coef: Optional[
         if (tuple(s1.shape[:3]) != (B, H, W_) or (s2 is not None and tuple(s2.shape[:3]) != (B, H, W_))
                 or tuple(sw.shape) != (Cout, SC1 + SC2) or sw.dtype != x1.dtype or s1.dtype != x1.dtype):
             raise ValueError("conv3x3_fused: projected input / weight shapes do not fit the output")
-        flops += 2.0 * B * H * W_ * Cout * (SC1 + SC2)
-    if fin is not None:
-        if not want_stats:
-            raise ValueError("conv3x3_fused: fin needs want_stats")
-        p2 = fin.get("partial2")
-        _dev(fin["gamma"], fin["beta"], p2)
-        C2f = 0 if p2 is None else p2.shape[2]
-        if fin["gamma"].numel() != Cout + C2f or fin["beta"].numel() != Cout + C2f:
-            raise ValueError("conv3x3_fused: GroupNorm gain/offset length does not match the consumer's channel count")
-        if p2 is not None and (p2.dtype != torch.float32 or p2.shape[0] != B or p2.shape[3] != 2 or not p2.is_contiguous()):
-            raise ValueError("conv3x3_fused: partial2 must be a contiguous fp32 (B, nsplit, C2, 2) slab")
-        gcoef = torch.empty((B, Cout + C2f, 2), dtype=torch.float32, device=x1.device)
-        ada = fin.get("ada")
-        f = _lib.GnFin(partial2=_ptr(p2), C2=C2f, nsplit2=0 if p2 is None else p2.shape[1], gamma=_ptr(fin["gamma"]),
-                       beta=_ptr(fin["beta"]), ada=None if ada is None else ada.data_ptr(),
-                       ada_stride=int(fin.get("ada_stride", 0)), coef=_ptr(gcoef), groups=int(fin["groups"]), HW=H * W_,
-                       eps=float(fin["eps"]), scale=float(fin.get("scale", 1.0)),
-                       counters=_ptr(_fin_counters(x1.device, B)))
-        end = TIMER.bracket("conv3x3_halo", flops)
-        check(lib.mad_conv3x3_fused_gn(_ptr(x1), C1, _ptr(x2), C2, _ptr(coef), mode, _ptr(w), _ptr(bias), _ptr(residual),
-                                       res_mode, _ptr(s1), SC1, _ptr(s2), SC2, _ptr(sw), _ptr(y), _ptr(stats), f,
-                                       _dtype_code(x1), B, H, W_, Cout, int(upsample), _stream()),
-              "mad_conv3x3_fused_gn")
-        if end is not None:
-            end.record()
-        return y, stats, gcoef
-    end = TIMER.bracket("conv3x3_halo", flops)
-    if skip is not None:
+        end = TIMER.bracket("conv3x3_halo", 2.0 * B * H * W_ * Cout * ((C1 + C2) * 9 + SC1 + SC2))
         check(lib.mad_conv3x3_fused_skip(_ptr(x1), C1, _ptr(x2), C2, _ptr(coef), mode, _ptr(w), _ptr(bias),
                                          _ptr(s1), SC1, _ptr(s2), SC2, _ptr(sw), _ptr(y), _ptr(stats),
                                          _dtype_code(x1), B, H, W_, Cout, _stream()), "mad_conv3x3_fused_skip")
-    else:
-        check(lib.mad_conv3x3_fused(_ptr(x1), C1, _ptr(x2), C2, _ptr(coef), mode, _ptr(w), _ptr(bias), _ptr(residual),
-                                    res_mode, _ptr(y), _ptr(stats), _dtype_code(x1), B, H, W_, Cout, int(upsample),
-                                    _stream()), "mad_conv3x3_fused")
+        if end is not None:
+            end.record()
+        return (y, stats) if want_stats else y
+    end = TIMER.bracket("conv3x3_halo", 2.0 * B * H * W_ * Cout * (C1 + C2) * 9)
+    check(lib.mad_conv3x3_fused(_ptr(x1), C1, _ptr(x2), C2, _ptr(coef), mode, _ptr(w), _ptr(bias), _ptr(residual),
+                                res_mode, _ptr(y), _ptr(stats), _dtype_code(x1), B, H, W_, Cout, int(upsample),
+                                _stream()), "mad_conv3x3_fused")
     if end is not None:
         end.record()
     return (y, stats) if want_stats else y

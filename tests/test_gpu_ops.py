@@ -438,55 +438,6 @@ def test_conv3x3_fused(dev, case, dt, bn, fmt, monkeypatch):
         assert torch.equal(c3, c1 * torch.tensor(_lib.PRESCALE_COEF, dtype=torch.float32))
 
 
-@pytest.mark.parametrize("case", [
-    # B, H, C1, Cout, fuse, C2 of the consumer's second slab, its splits, AdaGN, dtype
-    (3, 64, 64, 128, True, 0, 0, True, torch.bfloat16),        # 16 tiles x 4 channels per group: one-wave teams
-    (2, 256, 32, 128, True, 0, 0, True, torch.bfloat16),       # 256 tiles: four-wave teams (1024 items per group)
-    (2, 128, 64, 128, False, 128, 64, False, torch.bfloat16),  # consumer concatenates a skip: 8 x 64 = 512 items
-    (2, 64, 64, 256, True, 128, 16, False, torch.bfloat16),    # 384 channels: groups straddle the two slabs
-    (1, 32, 96, 192, False, 0, 0, True, torch.bfloat16),       # wide + narrow launch of one layer (192 channels)
-    (2, 32, 64, 64, True, 0, 0, False, torch.bfloat16),        # narrow loader-transform form: stand-alone kernel behind it
-    (2, 32, 64, 128, True, 64, 4, True, torch.float32),        # fp32: stand-alone kernel behind the launch
-])
-def test_conv3x3_fused_finishes_the_next_groupnorm(dev, case, monkeypatch):
-    """The conv call that also finishes the GroupNorm its output feeds (in the launch itself where the epilogue
-    allows, by the stand-alone kernel otherwise) against the two-call form: the same coefficients to the last bit,
-    with a second statistics slab, AdaGN rows and the prescale factor; twice in a row (the arrival counters are left at
-    zero) and with the in-launch form switched off."""
-    from mad_amd import _lib, ops
-    B, H, C1, Cout, fuse, C2f, ns2, with_ada, dt = case
-    monkeypatch.setenv("MAD_HALO_WIDE", "0")
-    x = _nhwc(_rand((B, C1, H, H), 31, 1.3) + 0.2, dt, dev)
-    w = _rand((Cout, C1, 3, 3), 32, 1.0 / math.sqrt(C1 * 9)).permute(0, 2, 3, 1).contiguous().to(dev)
-    wk = ops.halo_tile_weights(w, dt, _lib.PRESCALE_W if fuse else 1.0)
-    bias = _rand((Cout,), 33).to(dev)
-    coef = ((torch.stack([1 + 0.3 * _rand((B, C1), 34), 0.3 * _rand((B, C1), 35)], dim=-1) * _lib.PRESCALE_COEF)
-            .contiguous().to(dev)) if fuse else None
-    C = Cout + C2f
-    gamma, beta = (1 + 0.2 * _rand((C,), 36)).to(dev), (0.2 * _rand((C,), 37)).to(dev)
-    p2 = (_rand((B, ns2, C2f, 2), 38).abs() * 50).contiguous().to(dev) if C2f else None
-    if p2 is not None:
-        p2[..., 1] = p2[..., 0].abs() * 3 + 10                  # plausible sums of squares
-    ada = (0.3 * _rand((B, 2 * C + 5), 39)).contiguous().to(dev) if with_ada else None
-    groups = min(32, C // 4)
-    fin = dict(gamma=gamma, beta=beta, groups=groups, eps=1e-5, partial2=p2, scale=_lib.PRESCALE_COEF,
-               ada=None if ada is None else ada[:, 3:], ada_stride=0 if ada is None else ada.shape[1])
-
-    def run(**kw):
-        return ops.conv3x3_fused(x, wk, bias, coef=coef, act=True, want_stats=True, prescaled=fuse, w_tiled=True, **kw)
-
-    y0, s0 = run()
-    want = ops.gn_finalize(s0, H * H, gamma, beta, groups, 1e-5, ada=fin["ada"], ada_stride=fin["ada_stride"],
-                           partial2=p2, scale=_lib.PRESCALE_COEF)
-    for rep in range(2):
-        y1, s1, c1 = run(fin=fin)
-        assert torch.equal(y1, y0) and torch.equal(s1, s0)
-        assert torch.equal(c1, want), rep
-    assert int(ops._fin_counters(dev, B).abs().sum()) == 0
-    monkeypatch.setenv("MAD_GN_FOLD", "0")
-    assert torch.equal(run(fin=fin)[2], want)
-
-
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("bn", ["128", "64", "128w", "256"])
 @pytest.mark.parametrize("case", [(2, 32, 64, 64, 32, 128), (1, 16, 128, 96, 0, 192), (1, 64, 64, 32, 64, 256)])
