@@ -297,12 +297,14 @@ def main():
                           "launches": v["launches"]} for k, v in mfma.items()}
         # HBM bytes per launch of the dominant kernel come from separate PMC passes over this command
         # (tools/pmc_bench.sh); counters cannot be read from inside the timed run
-        traffic, traffic_src = None, None
+        traffic, traffic_src, traffic_build = None, None, None
         tfile = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_halo_traffic.json")
         if dom == "conv3x3_halo" and R == 256 and os.path.exists(tfile):
             with open(tfile) as f:
                 tj = json.load(f)
             traffic, traffic_src = tj.get("hbm_bytes_per_launch"), "profiles/pmc_halo_traffic.json (rocprofv3 --pmc FETCH_SIZE x2, WRITE_SIZE)"
+            # the counters are a property of the library they were taken on: say which, and whether it is this one
+            traffic_build = tj.get("build_id")
         line = {
             "metric": ("translated images/sec @256x256, fixed-step inversion+denoise (makeup removal)"
                        if R == 256 else f"translated images/sec @{R}x{R}, fixed-step inversion+denoise")
@@ -324,7 +326,8 @@ def main():
             "mfma_util_end_to_end": value * flops_img_eval * evals / 1e12 / (PEAK_BF16_TFLOPS * world),
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic, "traffic_unit": "bytes/launch",
-                         "traffic_source": traffic_src,
+                         "traffic_source": traffic_src, "traffic_build_id": traffic_build,
+                         "traffic_from_this_build": traffic_build == build_id if traffic_build else None,
                          "kernel": kernel_names.get(dom, dom),
                          "launches_timed": conv["launches"],
                          "avg_launch_ms": conv["ms"] / conv["launches"] if conv["launches"] else None,

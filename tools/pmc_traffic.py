@@ -2,7 +2,9 @@
 """Per-launch HBM traffic of the halo-tile conv from rocprofv3 --pmc csv output (FETCH_SIZE and WRITE_SIZE
 passes).  FETCH_SIZE is doubled: on gfx950 it tallies the 128-byte requests of wide coalesced reads at 64 bytes.
 Counter units are taken as reported by rocprofv3 for the derived metrics (KiB)."""
-import csv, glob, json, sys, collections
+import csv, glob, json, os, sys, collections
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mad_amd.buildid import library_build_id
 root = sys.argv[1]
 vals = collections.defaultdict(list)
 for f in glob.glob(f"{root}/*/**/*counter_collection.csv", recursive=True):
@@ -13,7 +15,8 @@ for f in glob.glob(f"{root}/*/**/*counter_collection.csv", recursive=True):
             if len(targs) >= 6 and targs[5] == "true":      # the NCHW-output form of the last layer
                 continue
             vals[r["Counter_Name"]].append(float(r["Counter_Value"]))
-out = {"kernel": "conv3x3_halo_kernel (all launches but the last layer)", "command": "bench.py --num-of-step 2"}
+out = {"kernel": "conv3x3_halo_kernel (all launches but the last layer)", "command": "bench.py --num-of-step 2",
+       "build_id": library_build_id()}      # the library the counters were taken on
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     v = vals.get(c, [])
     out[c + "_mean_raw"] = sum(v) / len(v) if v else None
