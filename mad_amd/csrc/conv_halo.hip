@@ -148,9 +148,14 @@ __device__ __forceinline__ void div2(float& t0, float& t1, float u0, float u1) {
         : "v"(u0), "v"(u1));
 }
 
-template <int BN, int TW> constexpr int halo_lds_bytes() {
-    constexpr int stage = 2 * halo_buf<TW>() + NWBUF * BN * HROW + 2 * CTAB_BYTES + 1024;   // + one sink KiB
-    constexpr int epi = 128 * (BN + 4) * 4;
+// staging buffers of one set of waves: two halo buffers, the weight-tile ring, two coefficient tables, one sink KiB
+template <int BN, int TW> constexpr int halo_stage_bytes() { return 2 * halo_buf<TW>() + NWBUF * BN * HROW + 2 * CTAB_BYTES + 1024; }
+// KS = 2: two sets of waves, each with its own staging buffers (see the kernel); their accumulator hand-over
+// (half of each wave's quads, 16 bytes per lane) fits the same space
+template <int BN, int TW, int KS = 1> constexpr int halo_lds_bytes() {
+    constexpr int stage = KS * halo_stage_bytes<BN, TW>();
+    constexpr int epi = KS == 1 ? 128 * (BN + 4) * 4 : 1024 * BN;
+    static_assert(KS == 1 || epi <= stage, "the hand-over of the two-share form fits its staging space");
 #ifdef MAD_HALO_STAMPS
     return (stage > epi ? stage : epi) + 4096;
 #else
@@ -161,11 +166,19 @@ template <int BN, int TW> constexpr int halo_lds_bytes() {
 // OUT_NCHW: write the first a.Cout (<= BN) channels as NCHW fp32 with bias (last layer).
 // PRE: the coefficient table holds (a, d) * -log2(e) and the weights carry a factor -ln(2): the loader computes
 // u = x*a' + d' and u / (1 + 2^u), which is -log2(e) * silu(x*a + d), one multiply-add per element less.
-template <typename T, bool FUSE, int WM, int WN, int TN, bool OUT_NCHW, bool SKIP, bool GSTAT, int TW = 16, bool PRE = false>
-__global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_halo_kernel(HaloArgs a) {
+// KS = 2 (two K shares in one workgroup): for layers whose tiles put no more than one workgroup on a CU.  The
+// workgroup is two sets of WM x WN waves; both own the same pixels and channels, set g multiplies the channel chunks
+// g, g + 2, ... out of staging buffers of its own (the loop below, unchanged, at twice the waves per SIMD), then the
+// sets exchange half of their accumulators through LDS and each finishes half of the rows.
+template <typename T, bool FUSE, int WM, int WN, int TN, bool OUT_NCHW, bool SKIP, bool GSTAT, int TW = 16, bool PRE = false,
+          int KS = 1>
+__global__ __launch_bounds__(64 * WM * WN * KS, KS == 2 ? 1 : 2) void conv3x3_halo_kernel(HaloArgs a) {
     static_assert(!PRE || (FUSE && !OUT_NCHW && !GSTAT), "the prescaled form belongs to the loader transform");
+    static_assert(KS == 1 || KS == 2, "one or two K shares");
+    // NWAVES, NT, `wave`, `tid` below: of ONE share (all the staging and fragment code is per share)
     constexpr int NWAVES = WM * WN, NT = 64 * NWAVES;
     static_assert(NWAVES == 4 || NWAVES == 8, "4 or 8 waves");
+    static_assert(KS == 1 || (NWAVES == 4 && TW == 16), "two shares of four waves");
     static_assert(TW == 16 || TW == 32, "tile width");
     constexpr int HSX = TW + 2;                    // halo columns
     constexpr int HALO_ITEMS = halo_items<TW>(), HALO_BUF = halo_buf<TW>();
@@ -183,20 +196,24 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_halo_kernel(HaloArgs 
     constexpr bool SLIDE = M16 && sizeof(T) == 2 && MAD_HALO_SLIDE;
     constexpr int NSLOT = TM16;
     constexpr bool DSE = M16 && sizeof(T) == 2 && !OUT_NCHW && !GSTAT && MAD_HALO_DSE;
+    static_assert(KS == 1 || DSE, "the two-share form finishes straight from the accumulators");
     constexpr int WTILE_BYTES = BN * HROW;
     constexpr int EPI_LD = BN + 4;
     constexpr int VEC = Elem<T>::VEC;
     constexpr int CK = HROW / (int)sizeof(T);      // channels per chunk: 32 (bf16) / 16 (fp32)
     constexpr int NW = (BN / 16 + NWAVES - 1) / NWAVES;   // weight DMA instructions per wave per K-tile
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* const halo0 = smem;
-    unsigned char* const wt0 = smem + 2 * HALO_BUF;
+    // the wave index is read into a scalar register: LDS destinations of the copies and everything else derived
+    // from it then live in scalar registers and cost no vector instructions
+    const int tid_all = threadIdx.x;
+    const int wave_all = __builtin_amdgcn_readfirstlane(tid_all >> 6);
+    const int grp = KS == 2 ? wave_all / NWAVES : 0;          // K share of this wave
+    const int tid = KS == 2 ? tid_all & (NT - 1) : tid_all, lane = tid & 63, wave = KS == 2 ? wave_all % NWAVES : wave_all;
+    unsigned char* const halo0 = smem + grp * halo_stage_bytes<BN, TW>();
+    unsigned char* const wt0 = halo0 + 2 * HALO_BUF;
     unsigned char* const ctab0 = wt0 + NWBUF * WTILE_BYTES;
     unsigned char* const sink0 = ctab0 + 2 * CTAB_BYTES;     // target of copies that only keep op counts equal
 
-    // the wave index is read into a scalar register: LDS destinations of the copies and everything else derived
-    // from it then live in scalar registers and cost no vector instructions
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
 
     // ---- tile coordinates (XCD-aware order: consecutive logical tiles share an L2)
@@ -212,7 +229,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_halo_kernel(HaloArgs 
     const int n0 = a.n_off + nt * BN;
 
     const int Ctot = a.C1 + a.C2;
-    const int nchunks = Ctot / CK;
+    const int nchunks = Ctot / CK;                 // of the layer; a share walks nchunks / KS of them:
+    auto gchunk = [&](int cc) { return cc * KS + grp; };      // its cc-th chunk is the layer's chunk gchunk(cc)
     // The accumulators start from the bias of their channels (the epilogue then has nothing to add); the NCHW form
     // adds it when it writes.  Register e of a lane: M16 channel 16*j + 4*fh + e; 32x32: 32*j + 8*(e/4) + 4*fh + e%4.
     // Requested here, ahead of the tile geometry, and pinned before the first copy is issued: an ordinary load
@@ -220,7 +238,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_halo_kernel(HaloArgs 
     constexpr int NB4 = M16 ? 2 * TN : 4 * TN;
     f32x4 bias4[NB4];
     {
-        const bool bias_init = !OUT_NCHW && a.bias != nullptr;
+        const bool bias_init = !OUT_NCHW && a.bias != nullptr && grp == 0;
         const int fh_ = M16 ? lane >> 4 : lane >> 5;
 #pragma unroll
         for (int k = 0; k < NB4; ++k) {
@@ -230,7 +248,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_halo_kernel(HaloArgs 
     }
 #ifdef MAD_HALO_STAMPS
     const unsigned long long clk_c0 = __builtin_readcyclecounter(), clk_r0 = __builtin_amdgcn_s_memrealtime();
-    unsigned* const stamp_lds = reinterpret_cast<unsigned*>(smem + halo_lds_bytes<BN, TW>() - 4096);
+    unsigned* const stamp_lds = reinterpret_cast<unsigned*>(smem + halo_lds_bytes<BN, TW, KS>() - 4096);
     const bool stamp_on = blockIdx.x == gridDim.x / 2 + 3;
     const int lane_ = threadIdx.x & 63, wave_ = threadIdx.x >> 6;
     if (stamp_on) {
@@ -291,7 +309,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_halo_kernel(HaloArgs 
     const unsigned halo_base = lds_addr(halo0);
     const unsigned sink_base = lds_addr(sink0);
     auto dma_item = [&](int cc, int j, int buf) {
-        const int c0 = cc * CK;
+        const int c0 = gchunk(cc) * CK;
         const T* src; int cs, coff;
         if (c0 < a.C1) { src = (const T*)a.x1; cs = a.C1; coff = c0; }
         else { src = (const T*)a.x2; cs = a.C2; coff = c0 - a.C1; }
@@ -318,7 +336,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_halo_kernel(HaloArgs 
     const unsigned ctab_base = lds_addr(ctab0);
     auto dma_coef = [&](int cc, int buf) {
         constexpr int LANES = CK * 8 / 16;          // 16 (bf16) / 8 (fp32) lanes carry the table
-        glds16s(a.coef + ((size_t)b * Ctot + cc * CK) * 2, (unsigned)(lane & (LANES - 1)) * 16u,
+        glds16s(a.coef + ((size_t)b * Ctot + gchunk(cc) * CK) * 2, (unsigned)(lane & (LANES - 1)) * 16u,
                 __builtin_amdgcn_readfirstlane(ctab_base + buf * CTAB_BYTES));
     };
     // exponent of the sigmoid: -t*log2(e) with the activation, -200 without it (exp2 gives 0, the reciprocal
@@ -466,7 +484,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_halo_kernel(HaloArgs 
         const int lchunk = (lane & 3) ^ ((-(r >> 2)) & 3);
         wrow_off[j] = a.wtiled ? (unsigned)lane * 16u : (unsigned)((r * 9 * Ctot + lchunk * VEC) * (int)sizeof(T));
     }
-    auto stage_w = [&](int cc, int pos, int buf) {
+    auto stage_w = [&](int cc_share, int pos, int buf) {
+        const int cc = gchunk(cc_share);
         // K-tiles of a chunk are multiplied column by column of the 3x3 window (loop position pos: kx = pos / 3,
         // ky = pos % 3; see the chunk body), the weights are stored row by row (tap = ky * 3 + kx)
         const int tap = (pos % 3) * 3 + pos / 3;
@@ -790,8 +809,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_halo_kernel(HaloArgs 
             MAD_STAMP(4)
         }
     };
-    for (int cc = 0; cc < nchunks - 1; ++cc) chunk_body(cc, std::false_type{});
-    chunk_body(nchunks - 1, std::true_type{});
+    for (int cc = 0; cc < nchunks / KS - 1; ++cc) chunk_body(cc, std::false_type{});
+    chunk_body(nchunks / KS - 1, std::true_type{});
     dma_wait_all();
     if constexpr (SLIDE && MAD_HALO_ASM_MMA) {
         // the products above are asm statements: the compiler does not know that the accumulators are results of
@@ -805,10 +824,10 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_halo_kernel(HaloArgs 
     // ((p>>2)&3), the weight-tile layout), two buffers, one chunk in flight while one is multiplied.
     if constexpr (SKIP) {
         const int Cs = a.SC1 + a.SC2;
-        const int nskip = Cs / CK;
+        const int nskip = Cs / CK / KS;            // per share
         constexpr int SK_ROUNDS = TW * 16 * 4 / NT;      // pixels in the order (half, row, column)
         auto dma_skip = [&](int sc, int buf) {
-            const int c0 = sc * CK;
+            const int c0 = gchunk(sc) * CK;
             const T* src; int cs, coff;
             if (c0 < a.SC1) { src = (const T*)a.sx1; cs = a.SC1; coff = c0; }
             else { src = (const T*)a.sx2; cs = a.SC2; coff = c0 - a.SC1; }
@@ -929,6 +948,39 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_halo_kernel(HaloArgs 
         // sums by v_dot2c_f32_bf16 on the packed output), then over the 16 pixel columns by a DPP butterfly, then over
         // the waves that share channels through LDS in wave order: a fixed order, so results are deterministic.
         constexpr int NP = TN16 / 2;                    // pairs of 16-channel blocks per wave
+        constexpr int TMR = TM16 / KS;                  // rows this wave finishes
+        if constexpr (KS == 2) {
+            // The two shares hold partial sums of the same pixels and channels.  Share 0 finishes the first TMR rows of
+            // a wave's TM16, share 1 the others: each hands the quads of the rows it does not finish to the wave with
+            // its number in the other share (16 bytes per lane and quad, lane-linear), adds what it receives, and
+            // share 1 moves its rows into the first TMR register rows so that the code below is the same for both.
+            __syncthreads();                            // every wave is done with the staging buffers
+            f32x4* xch = reinterpret_cast<f32x4*>(smem);
+            auto slot = [&](int g, int i, int j) { return xch + (((g * NWAVES + wave) * TMR + i) * TN16 + j) * 64 + lane; };
+            if (grp == 0) {
+#pragma unroll
+                for (int i = 0; i < TMR; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN16; ++j) *slot(0, i, j) = acc16[TMR + i][j];
+            } else {
+#pragma unroll
+                for (int i = 0; i < TMR; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN16; ++j) *slot(1, i, j) = acc16[i][j];
+            }
+            __syncthreads();
+            if (grp == 0) {
+#pragma unroll
+                for (int i = 0; i < TMR; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN16; ++j) acc16[i][j] += *slot(1, i, j);
+            } else {
+#pragma unroll
+                for (int i = 0; i < TMR; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN16; ++j) acc16[i][j] = *slot(0, i, j) + acc16[TMR + i][j];
+            }
+        }
         const T* res = (const T*)a.residual;
         T* y = (T*)a.y;
         const int cb0 = wn * (TN * 32) + (fh & 1) * 16 + (fh >> 1) * 8;     // this lane's first channel, pair 0
@@ -941,10 +993,10 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_halo_kernel(HaloArgs 
         const int ox = tx0 + half * 16 + fr;
         const bool has_res = a.res_mode == MAD_RES_SAME || a.res_mode == MAD_RES_UP;
         constexpr int RG = 4;                           // rows per group of residual requests
-        static_assert(TM16 % RG == 0, "whole row groups");
-        auto row_y = [&](int i) { return ty0 + (((wm * WAVE_PIX) >> 4) & 15) + i; };
+        static_assert(TMR % RG == 0, "whole row groups");
+        auto row_y = [&](int i) { return ty0 + (((wm * WAVE_PIX) >> 4) & 15) + grp * TMR + i; };
 #pragma unroll
-        for (int i0 = 0; i0 < TM16; i0 += RG) {
+        for (int i0 = 0; i0 < TMR; i0 += RG) {
             uint4 rpre[RG][NP];
             if (has_res) {
 #pragma unroll
@@ -1022,22 +1074,22 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_halo_kernel(HaloArgs 
 #pragma unroll
                 for (int k = 0; k < 4; ++k) { ssum[p][k] = row16_sum(ssum[p][k]); ssq[p][k] = row16_sum(ssq[p][k]); }
             __syncthreads();                              // every wave is done with the staging buffers
-            float* red = reinterpret_cast<float*>(smem);  // [WM][BN / 2 channel pairs][2]
+            float* red = reinterpret_cast<float*>(smem);  // [KS * WM][BN / 2 channel pairs][2]
             if (fr == 0) {
 #pragma unroll
                 for (int p = 0; p < NP; ++p)
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         const int pr = (cb0 + p * 32) / 2 + k;
-                        red[(wm * (BN / 2) + pr) * 2] = ssum[p][k];
-                        red[(wm * (BN / 2) + pr) * 2 + 1] = ssq[p][k];
+                        red[((grp * WM + wm) * (BN / 2) + pr) * 2] = ssum[p][k];
+                        red[((grp * WM + wm) * (BN / 2) + pr) * 2 + 1] = ssq[p][k];
                     }
             }
             __syncthreads();
-            if (tid < BN / 2) {
+            if (tid_all < BN / 2) {
                 float sm = 0.0f, sq = 0.0f;
 #pragma unroll
-                for (int w = 0; w < WM; ++w) { sm += red[(w * (BN / 2) + tid) * 2]; sq += red[(w * (BN / 2) + tid) * 2 + 1]; }
+                for (int w = 0; w < KS * WM; ++w) { sm += red[(w * (BN / 2) + tid) * 2]; sq += red[(w * (BN / 2) + tid) * 2 + 1]; }
                 // one row of sums per 16x16 tile of the image, per channel pair: (sum, sum of squares) in the slot of the
                 // even channel, zeros in the slot of the odd one; a 32-wide tile writes its sums to the row of its left
                 // half and zeros to the row of its right half (the consumer adds the rows up)
@@ -1231,17 +1283,17 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_halo_kernel(HaloArgs 
 }
 
 template <typename T, bool FUSE, int WM, int WN, int TN, bool OUT_NCHW, bool SKIP = false, bool GSTAT = false, int TW = 16,
-          bool PRE = false>
+          bool PRE = false, int KS = 1>
 static int launch_halo(const HaloArgs& a0, hipStream_t s, const char* what) {
-    constexpr int lds = halo_lds_bytes<WN * TN * 32, TW>();
+    constexpr int lds = halo_lds_bytes<WN * TN * 32, TW, KS>();
     static int lds_dev = -1;
-    MAD_REQUIRE(raise_lds_limit(reinterpret_cast<const void*>(&conv3x3_halo_kernel<T, FUSE, WM, WN, TN, OUT_NCHW, SKIP, GSTAT, TW, PRE>),
+    MAD_REQUIRE(raise_lds_limit(reinterpret_cast<const void*>(&conv3x3_halo_kernel<T, FUSE, WM, WN, TN, OUT_NCHW, SKIP, GSTAT, TW, PRE, KS>),
                                 lds, &lds_dev),
                 "%s: cannot raise the dynamic LDS limit to %d", what, lds);
     HaloArgs a = a0;
     a.tiles_x = a.W / TW;
     const int grid = a.B * a.tiles_x * a.tiles_y * a.ntiles_n;
-    hipLaunchKernelGGL((conv3x3_halo_kernel<T, FUSE, WM, WN, TN, OUT_NCHW, SKIP, GSTAT, TW, PRE>), dim3(grid), dim3(64 * WM * WN), lds, s, a);
+    hipLaunchKernelGGL((conv3x3_halo_kernel<T, FUSE, WM, WN, TN, OUT_NCHW, SKIP, GSTAT, TW, PRE, KS>), dim3(grid), dim3(64 * WM * WN * KS), lds, s, a);
     return check_launch(what);
 }
 
@@ -1329,7 +1381,24 @@ static int conv3x3_fused_impl(const void* x1, int C1, const void* x2, int C2, co
     bool bn256 = bn256_fits && B * a.tiles_x * a.tiles_y * (Cout / 256) >= 256;
     if (const char* f = getenv("MAD_HALO_BN256"))            // tuning / test aid: 0 = never, 2 = wherever it fits
         bn256 = atoi(f) == 2 ? bn256_fits : (bn256 && atoi(f) != 0);
+    // Two K shares per workgroup (eight waves) where the tiles put no more than one four-wave workgroup on a CU:
+    // the low-resolution layers of a small batch.  bf16, output written straight from the accumulators (no loader
+    // transform, or the prescaled one at 128 channels per workgroup), whole pairs of channel chunks.
+    const int grid1 = B * a.tiles_x * a.tiles_y * (Cout / (mode == 128 ? 128 : 64));
+    const bool ks2_fits = dtype == MAD_BF16 && !gn && !wide_ok && !bn256 && mode != 192 && (!coef || (pre && mode == 128)) &&
+                          (C1 + C2) % 64 == 0 && (SC1 + SC2) % 64 == 0;
+    bool ks2 = ks2_fits && grid1 <= 256;
+    if (const char* f = getenv("MAD_HALO_KS"))               // tuning / test aid: 0 = never, 2 = wherever it fits
+        ks2 = atoi(f) == 2 ? ks2_fits : (ks2 && atoi(f) != 0);
     auto run = [&](bool narrow) -> int {
+        if (ks2) {
+            if (coef) return SC1 > 0 ? launch_halo<bf16_t, true, 2, 2, 2, false, true, false, 16, true, 2>(a, s, what)
+                                     : launch_halo<bf16_t, true, 2, 2, 2, false, false, false, 16, true, 2>(a, s, what);
+            if (narrow) return SC1 > 0 ? launch_halo<bf16_t, false, 2, 2, 1, false, true, false, 16, false, 2>(a, s, what)
+                                       : launch_halo<bf16_t, false, 2, 2, 1, false, false, false, 16, false, 2>(a, s, what);
+            return SC1 > 0 ? launch_halo<bf16_t, false, 2, 2, 2, false, true, false, 16, false, 2>(a, s, what)
+                           : launch_halo<bf16_t, false, 2, 2, 2, false, false, false, 16, false, 2>(a, s, what);
+        }
         if (wide_ok && !narrow) {
             if (SC1 > 0)
                 return coef ? launch_halo<bf16_t, true, 4, 2, 2, false, true, false, 32>(a, s, what)

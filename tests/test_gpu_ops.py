@@ -350,12 +350,14 @@ FUSED_CASES = [
     (2, 32, 64, 32, 320, True, False, "same", True),      # 2 x 128 + 64 output channels, two sources
     (1, 32, 64, 0, 256, True, False, "same", True),       # one 256-channel workgroup column ("256")
     (1, 32, 96, 32, 512, True, True, "up", True),         # two of them, two sources, nearest x2
+    (2, 16, 128, 0, 128, False, False, "same", True),     # plain input, one tile per image
+    (1, 32, 64, 64, 192, False, True, "up", True),        # plain, two sources, nearest x2, odd multiple of 64 channels
 ]
 
 
 @pytest.mark.parametrize("case", FUSED_CASES)
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("bn", ["128", "64", "192", "128w", "192w", "256"])
+@pytest.mark.parametrize("bn", ["128", "64", "192", "128w", "192w", "256", "ks2", "ks2n"])
 @pytest.mark.parametrize("fmt", ["plain", "tiled", "tiled+pre"])
 def test_conv3x3_fused(dev, case, dt, bn, fmt, monkeypatch):
     """Both workgroup widths (128 and 64 output channels) of the halo-tile kernel, ("192") the split of an
@@ -363,11 +365,21 @@ def test_conv3x3_fused(dev, case, dt, bn, fmt, monkeypatch):
     forced wherever they fit (bf16, width a multiple of 32, 128-channel workgroups), and ("256") the eight-wave
     256-channel workgroups of the prescaled loader-transform form forced likewise.  fmt: the weights as
     (Cout,3,3,Cin), tile by tile, and tile by tile with the loader transform in its prescaled form (coefficients
-    times -log2(e), weights times -ln(2)): the same convolution every time."""
+    times -log2(e), weights times -ln(2)): the same convolution every time.  ("ks2" / "ks2n") the eight-wave form
+    whose two sets of waves split the channel chunks, at 128 / 64 output channels per workgroup, forced wherever it
+    fits (bf16; plain input or the prescaled transform at 128 channels; whole pairs of chunks); every other value
+    of bn runs with that form switched off, so that the small shapes here still reach the four-wave forms."""
     from mad_amd import _lib, ops
+    B, H, C1, C2, Cout, fuse, up, res, want_stats = case
+    monkeypatch.setenv("MAD_HALO_KS", "2" if bn.startswith("ks2") else "0")
+    if bn.startswith("ks2"):
+        if dt != torch.bfloat16 or (C1 + C2) % 64 or (fuse and (fmt != "tiled+pre" or bn == "ks2n")):
+            pytest.skip("two K shares: bf16, whole chunk pairs, plain input or the prescaled transform at 128 channels")
+        if bn == "ks2" and Cout % 128:
+            pytest.skip("128-channel workgroups")
+        bn = "128" if bn == "ks2" else "64"
     wide = bn.endswith("w")
     bn = bn.rstrip("w")
-    B, H, C1, C2, Cout, fuse, up, res, want_stats = case
     monkeypatch.setenv("MAD_HALO_BN256", "2" if bn == "256" else "0")
     if bn == "256":
         if dt != torch.bfloat16 or fmt != "tiled+pre" or not fuse or Cout % 256:
@@ -439,16 +451,25 @@ def test_conv3x3_fused(dev, case, dt, bn, fmt, monkeypatch):
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("bn", ["128", "64", "128w", "256"])
-@pytest.mark.parametrize("case", [(2, 32, 64, 64, 32, 128), (1, 16, 128, 96, 0, 192), (1, 64, 64, 32, 64, 256)])
-@pytest.mark.parametrize("fmt", ["plain", "tiled+pre"])
+@pytest.mark.parametrize("bn", ["128", "64", "128w", "256", "ks2", "ks2n"])
+@pytest.mark.parametrize("case", [(2, 32, 64, 64, 32, 128), (1, 16, 128, 96, 0, 192), (1, 64, 64, 32, 64, 256),
+                                  (2, 32, 128, 64, 64, 128), (2, 16, 192, 128, 0, 192)])
+@pytest.mark.parametrize("fmt", ["plain", "tiled+pre", "nocoef"])
 def test_conv3x3_fused_projection(dev, case, dt, bn, fmt, monkeypatch):
     """conv1 + the residual branch's 1x1 projection of the (two-source) block input in one launch (fmt and bn as in
-    test_conv3x3_fused; the projection's weights are never scaled)."""
+    test_conv3x3_fused; the projection's weights are never scaled; "nocoef": a plain conv input, as the blocks
+    below the loader transform's resolution pass it)."""
     from mad_amd import _lib, ops
+    B, H, C, S1, S2, Cout = case
+    monkeypatch.setenv("MAD_HALO_KS", "2" if bn.startswith("ks2") else "0")
+    if bn.startswith("ks2"):
+        if dt != torch.bfloat16 or C % 64 or (S1 + S2) % 64 or fmt == "plain" or (fmt == "tiled+pre" and bn == "ks2n"):
+            pytest.skip("two K shares: bf16, whole chunk pairs, plain input or the prescaled transform at 128 channels")
+        if bn == "ks2" and Cout % 128:
+            pytest.skip("128-channel workgroups")
+        bn = "128" if bn == "ks2" else "64"
     monkeypatch.setenv("MAD_HALO_WIDE", "2" if bn.endswith("w") else "0")
     bn = bn.rstrip("w")
-    B, H, C, S1, S2, Cout = case
     monkeypatch.setenv("MAD_HALO_BN256", "2" if bn == "256" else "0")
     if bn == "256":
         if dt != torch.bfloat16 or fmt != "tiled+pre" or Cout % 256:
@@ -462,7 +483,8 @@ def test_conv3x3_fused_projection(dev, case, dt, bn, fmt, monkeypatch):
     bias = _rand((Cout,), 6)
     coef = torch.stack([1 + 0.3 * _rand((B, C), 7), 0.3 * _rand((B, C), 8)], dim=-1)
     q = (lambda t: t.to(dt).float()) if dt == torch.bfloat16 else (lambda t: t)
-    hin = F.silu(q(h) * coef[:, :, 0, None, None] + coef[:, :, 1, None, None])
+    nocoef = fmt == "nocoef"
+    hin = q(h) if nocoef else F.silu(q(h) * coef[:, :, 0, None, None] + coef[:, :, 1, None, None])
     if dt == torch.bfloat16:
         hin = q(hin)                                           # the loader rounds the activated value
     sin = q(s1) if s2 is None else torch.cat([q(s1), q(s2)], 1)
@@ -471,7 +493,8 @@ def test_conv3x3_fused_projection(dev, case, dt, bn, fmt, monkeypatch):
     wk = w.permute(0, 2, 3, 1).contiguous().to(dev)
     wk = ops.halo_tile_weights(wk, dt, _lib.PRESCALE_W) if pre else wk.to(dt)
     y, stats = ops.conv3x3_fused(_nhwc(h, dt, dev), wk, bias.to(dev),
-                                 coef=(coef * _lib.PRESCALE_COEF if pre else coef).to(dev), act=True, want_stats=True,
+                                 coef=None if nocoef else (coef * _lib.PRESCALE_COEF if pre else coef).to(dev),
+                                 act=True, want_stats=True,
                                  skip=(_nhwc(s1, dt, dev), None if s2 is None else _nhwc(s2, dt, dev),
                                        sw.reshape(Cout, -1).to(dt).to(dev)), prescaled=pre, w_tiled=pre)
     assert rel_err(_nchw(y), want) < (2e-5 if dt == torch.float32 else 8e-3)
