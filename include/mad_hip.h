@@ -159,8 +159,11 @@ int mad_conv2d(const void* x1, int C1, const void* x2, int C2, const void* w, co
 
 /* mad_conv2d that also writes the GroupNorm partial sums of its output: stats fp32 (B*H*W/64, Cout, 2),
  * per-channel sum / sum of squares of every run of 64 consecutive output pixels (H*W a multiple of
- * 64), i.e. (B, nsplit = H*W/64, Cout, 2) as mad_gn_finalize consumes it.  Replaces the statistics
- * pass of the GroupNorm that follows the convolution (model.py:182-190). */
+ * 64), i.e. (B, nsplit = H*W/64, Cout, 2) as mad_gn_finalize consumes it.  bf16 1x1 layers that run on the
+ * 256-pixel-tile GEMM kernel hold, as mad_conv3x3_fused does, the sums of channels 2i and 2i+1 together in
+ * slot 2i and zeros in slot 2i+1: use the slab for sums over groups of whole channel pairs only (GroupNorm
+ * groups with an even channel count).  Replaces the statistics pass of the GroupNorm that follows the
+ * convolution (model.py:182-190). */
 int mad_conv2d_stats(const void* x1, int C1, const void* x2, int C2, const void* w, const float* bias,
                      const void* residual, int res_mode, void* y, float* stats, int dtype, int B, int H,
                      int W, int Cout, int ksize, int upsample, void* stream);

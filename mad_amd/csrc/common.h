@@ -17,6 +17,12 @@ bool conv_out_taps_ok(int Cin, int H, int W, int Cout);
 int conv_out_taps(const void* x, int Cin, const float* coef, int act, const void* w, const float* bias, float* y, int B,
                   int H, int W, int Cout, hipStream_t s);
 
+// 1x1 convolution as a GEMM on 256-pixel tiles (conv1x1.hip): bf16, M = B*H*W pixels, optional same-size residual
+// and per-64-pixel-run statistics
+bool conv1x1_ok(int M, int C1, int C2, int Cout);
+int conv1x1(const void* x1, int C1, const void* x2, int C2, const void* w, const float* bias, const void* residual,
+            void* y, float* stats, int M, int Cout, hipStream_t s);
+
 #define MAD_REQUIRE(cond, ...)              \
     do {                                    \
         if (!(cond)) {                      \

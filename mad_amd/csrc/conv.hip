@@ -784,6 +784,10 @@ static int conv2d_impl(const void* x1, int C1, const void* x2, int C2, const voi
     MAD_REQUIRE(!stats || (H * W) % 64 == 0, "mad_conv2d_stats: H*W=%d must be a multiple of 64", H * W);
     a.Hs = upsample ? H / 2 : H; a.Ws = upsample ? W / 2 : W;
     hipStream_t s = (hipStream_t)stream;
+    // 1x1 layers with enough pixels: the 256-pixel-tile GEMM
+    if (dtype == MAD_BF16 && ksize == 1 && !upsample && !a.partial && (res_mode == MAD_RES_NONE || res_mode == MAD_RES_SAME) &&
+        conv1x1_ok(a.M, C1, C2, Cout))
+        return conv1x1(x1, C1, a.x2, C2, w, bias, residual, y, stats, a.M, Cout, s);
     return dtype == MAD_BF16 ? dispatch_igemm<bf16_t>(a, s) : dispatch_igemm<float>(a, s);
 }
 

@@ -1063,6 +1063,9 @@ __global__ __launch_bounds__(64 * WM * WN * KS, KS == 2 ? 1 : 2) void conv3x3_ha
         if (a.stats) {
             // over the 16 pixel columns: lanes ^1, ^2 inside a quad, then the mirrored quad, then the mirrored half row
             auto row16_sum = [](float x) {
+                // x may come straight out of an asm statement (the dot products above), where the compiler does not see a
+                // vector write: the two wait states a DPP read of a freshly written register needs are provided here
+                asm volatile("s_nop 1" : "+v"(x));
                 x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, true));
                 x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xF, 0xF, true));
                 x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x141, 0xF, 0xF, true));

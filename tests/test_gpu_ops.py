@@ -184,17 +184,25 @@ CONV_CASES = [
     (2, 64, 128, 0, 128, 3, False, "same"),     # several tiles, several rows per tile
     (16, 8, 256, 0, 256, 3, False, "same"),     # few tiles, long K: the dispatcher cuts K into shares by itself
     (3, 8, 128, 64, 128, 1, False, "same"),     # 1x1 over a concat, M = 192: a whole tile (scalar-base loader) + a partial one
+    (2, 32, 192, 64, 256, 1, False, "same"),    # 1x1, eight 256-pixel tiles, two sources
 ]
 
 
 @pytest.mark.parametrize("case", CONV_CASES)
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("tile", ["auto", "128x128x2", "128x64x2", "64x128x3", "split3"])
+@pytest.mark.parametrize("tile", ["auto", "128x128x2", "128x64x2", "64x128x3", "split3", "gemm"])
 def test_conv2d(dev, case, dt, tile, monkeypatch):
-    """Every block-tile variant the dispatcher can pick (small inputs alone would only reach 64x64), and the
-    split-K form (three shares of the K-tiles, some of them empty for the short layers)."""
+    """Every block-tile variant the dispatcher can pick (small inputs alone would only reach 64x64), the
+    split-K form (three shares of the K-tiles, some of them empty for the short layers), and ("gemm") the
+    256-pixel-tile GEMM of the 1x1 layers forced wherever it fits."""
     from mad_amd import _lib, ops
-    if tile == "split3":
+    gemm = tile.startswith("gemm")
+    if gemm:
+        B, H, C1, C2, Cout, k, up, res = case
+        if dt != torch.bfloat16 or k != 1 or up or res not in ("none", "same") or Cout % 128:
+            pytest.skip("1x1 GEMM form: bf16, 1x1, no resampling, 128 output channels per workgroup")
+        monkeypatch.setenv("MAD_CONV1X1", "2")
+    elif tile == "split3":
         monkeypatch.setenv("MAD_IGEMM_KSPLIT", "3")
     elif tile != "auto":
         monkeypatch.setenv("MAD_IGEMM_TILE", tile)
@@ -231,8 +239,10 @@ def test_conv2d(dev, case, dt, tile, monkeypatch):
                            want_stats=True)
     assert torch.equal(y2, y) and tuple(stats.shape) == (B, H * H // 64, Cout, 2)
     runs = y.float().reshape(B, H * H // 64, 64, Cout)
-    assert rel_err(stats[..., 0].cpu(), runs.sum(2).cpu()) < 1e-4
-    assert rel_err(stats[..., 1].cpu(), (runs * runs).sum(2).cpu()) < 1e-4
+    # (the bf16 GEMM form keeps the sums of a channel pair in its even slot: a GroupNorm group holds whole pairs)
+    cpair = (lambda t: t.reshape(*t.shape[:-1], Cout // 2, 2).sum(-1)) if gemm else (lambda t: t)
+    assert rel_err(cpair(stats[..., 0].cpu()), cpair(runs.sum(2).cpu())) < 1e-4
+    assert rel_err(cpair(stats[..., 1].cpu()), cpair((runs * runs).sum(2).cpu())) < 1e-4
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
