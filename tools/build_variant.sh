@@ -6,9 +6,9 @@ cd "$(dirname "$0")/../mad_amd/csrc"
 name=$1; src=$2; shift 2
 make -s -j8
 obj=/tmp/variant_${name}_$(basename $src .hip).o
-hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-value "$@" -c $src -o $obj
+hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-value -Wno-inline-asm "$@" -c $src -o $obj
 objs=""
-for o in api.o sampler.o linear.o groupnorm.o groupnorm_bwd.o conv.o conv_halo.o conv_out.o conv_img8.o wgrad.o attention.o attention_bwd.o train_ops.o; do
+for o in $(sed -n 's/^OBJS *:= *//p' Makefile); do
   if [ "$o" = "$(basename $src .hip).o" ]; then objs="$objs $obj"; else objs="$objs $o"; fi
 done
 hipcc -shared -fPIC --offload-arch=gfx950 -o ../libmad_hip_${name}.so $objs
