@@ -22,6 +22,17 @@
 //            residual; sum / sum of squares of the stored values go to a (B, tiles, Cout, 2) slab in a
 //            fixed order (deterministic).  fp32: per channel.  bf16: per channel PAIR (2i, 2i+1), both sums in
 //            slot 2i and zeros in slot 2i+1 -- a GroupNorm group holds whole pairs and only group sums are used.
+//   bf16 on the 16x16x32 MFMA (the forms the denoiser runs in; the description above is the 32x32x16 / fp32 form):
+//            the weights are the first operand, so a lane's four results are four consecutive channels of a pixel.
+//            The window is walked column by column and a wave's eight pixel-row fragments stay in registers across
+//            the three vertical taps (one new row per tap: 30 + 36 instead of 72 + 36 fragment reads per chunk);
+//            the products are asm statements that accumulate in place; the output goes straight from the
+//            accumulators to memory (lane pairs exchange quads with v_permlane16_swap: eight consecutive channels,
+//            one 16-byte store per lane), statistics by v_dot2c_f32_bf16 per lane, DPP across the 16 pixel
+//            columns and 1 KiB of LDS across waves -- no tile hand-over, no barrier between products and stores.
+//            KS = 2: layers whose tiles put at most one workgroup on a CU run eight waves, two sets of four that
+//            multiply alternate channel chunks out of their own staging buffers and then exchange half of their
+//            accumulators, each set finishing half of the rows.
 #include "mma.h"
 #include <cstdlib>
 #include <type_traits>
